@@ -1,0 +1,694 @@
+/*
+ * iris_oracle.c -- CPU ORACLE for the bake_shading hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.  The product (iris_amd/,
+ * libiris_hip.so) never links, imports or calls anything in oracle/.
+ *
+ * It is a plain-C restatement of the reference's algorithm (IEEE f32 arithmetic, libm
+ * transcendentals), every function citing the reference file:line it follows.
+ *
+ * Pinning status
+ *   - a1 ray generation, a3/a4 BRDF samplers, a5 VoxelSLF / SLFEmitter.eval_emitter, a6 MC
+ *     reduction, a10 lerp_specular: PINNED against golden vectors produced by importing the
+ *     reference's own Python (tools/make_goldens.py -> tests/golden/ npz files).
+ *   - a2 ray/mesh intersection: PARITY UNPINNED.  The reference delegates it to Mitsuba 3.5.0
+ *     (cuda_ad_rgb / OptiX; environment.yml:14-15), whose source is not under /root/reference
+ *     and which the reference has no test vectors for.  We restate Mitsuba 3's published
+ *     triangle routine (Moeller-Trumbore as in mitsuba3 include/mitsuba/render/mesh.h
+ *     `ray_intersect_triangle_impl`) and its Mesh::compute_surface_interaction conventions
+ *     (si.p = barycentric interpolation, si.n = unit geometric normal, si.uv = (b1,b2) when the
+ *     mesh carries no texcoords, t = +inf on a miss), anchored on the reference's call site
+ *     utils/path_tracing.py:17-48.
+ *
+ * Arithmetic contract for the intersection (so that a different implementation can be compared
+ * bit for bit): all operations are IEEE-754 binary32, no contraction other than the explicit
+ * fmaf() calls written below (compile with -ffp-contract=off):
+ *     cross(a,b) = ( fma(a.y,b.z,-(a.z*b.y)), fma(a.z,b.x,-(a.x*b.z)), fma(a.x,b.y,-(a.y*b.x)) )
+ *     dot(a,b)   = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+ * Closest hit = lexicographic minimum of (t, triangle index) over all triangles that pass the test.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_ld(const float *p) { return v3_make(p[0], p[1], p[2]); }
+static inline void v3_st(float *p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+/* ---- arithmetic contract (see header) ---- */
+static inline v3 x_cross(v3 a, v3 b) {
+    return v3_make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline float x_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+
+/* torch-style helpers: sum over the last dim in index order, no fma */
+static inline float t_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* NF.normalize(v,dim=-1): v / max(||v||_2, 1e-12) */
+static inline v3 t_normalize(v3 a) {
+    float n = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+    if (n < 1e-12f) n = 1e-12f;
+    return v3_make(a.x / n, a.y / n, a.z / n);
+}
+/* torch.cross(a,b,dim=-1) */
+static inline v3 t_cross(v3 a, v3 b) {
+    return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float relu(float x) { return x > 0.f ? x : 0.f; }
+
+static const float PI_F = 3.14159265358979323846f;      /* float32(math.pi)   */
+static const float TWO_PI_F = 6.28318530717958647692f;  /* float32(2*math.pi) */
+
+/* ============================================================================================
+ * a1  ray generation
+ * ========================================================================================== */
+
+/* utils/dataset/real_ldr.py:49-61 get_direction + :63-83 to_world (also the ScanNet++ loader,
+ * utils/dataset/scannetpp/dataset.py:202-215).  K row-major 3x3, c2w row-major 3x4.
+ * rays_o/rays_d: (H*W,3) row-major, x fastest.  ray_diff!=0: un-normalised d plus dxdu,dydv. */
+ORC_API void orc_raygen_real(const float *K, const float *c2w, int H, int W, int ray_diff,
+                             float *rays_o, float *rays_d, float *dxdu, float *dydv) {
+    const float fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int64_t i = (int64_t)y * W + x;
+            /* torch.linspace(0.5,N-0.5,N) has step exactly 1 -> pixel centre x+0.5 */
+            float dc[3] = {((float)x + 0.5f - cx) / fx, ((float)y + 0.5f - cy) / fy, 1.0f};
+            v3 d;
+            /* rays_d @ c2w[:3,:3].T  -> d[i] = sum_j dc[j]*R[i][j] */
+            d.x = (dc[0] * c2w[0] + dc[1] * c2w[1]) + dc[2] * c2w[2];
+            d.y = (dc[0] * c2w[4] + dc[1] * c2w[5]) + dc[2] * c2w[6];
+            d.z = (dc[0] * c2w[8] + dc[1] * c2w[9]) + dc[2] * c2w[10];
+            rays_o[i * 3 + 0] = c2w[3]; rays_o[i * 3 + 1] = c2w[7]; rays_o[i * 3 + 2] = c2w[11];
+            if (ray_diff) {
+                v3_st(rays_d + i * 3, d);
+                float ifx = 1.0f / fx, ify = 1.0f / fy;
+                dxdu[i * 3 + 0] = ifx * c2w[0]; dxdu[i * 3 + 1] = ifx * c2w[4]; dxdu[i * 3 + 2] = ifx * c2w[8];
+                dydv[i * 3 + 0] = ify * c2w[1]; dydv[i * 3 + 1] = ify * c2w[5]; dydv[i * 3 + 2] = ify * c2w[9];
+            } else {
+                v3_st(rays_d + i * 3, t_normalize(d));
+            }
+        }
+}
+
+/* utils/dataset/synthetic_ldr.py:21-34 get_ray_directions + :36-57 get_rays.
+ * focal_diff!=0 corresponds to get_rays(..., focal=focal): un-normalised d + differentials. */
+ORC_API void orc_raygen_synthetic(float focal, const float *c2w, int H, int W, int ray_diff,
+                                  float *rays_o, float *rays_d, float *dxdu, float *dydv) {
+    /* W/2 and H/2 are python float divisions */
+    const float hw = (float)((double)W / 2.0), hh = (float)((double)H / 2.0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int64_t i = (int64_t)y * W + x;
+            float dc[3] = {-(((float)x + 0.5f) - hw) / focal, -(((float)y + 0.5f) - hh) / focal, 1.0f};
+            v3 d;
+            d.x = (dc[0] * c2w[0] + dc[1] * c2w[1]) + dc[2] * c2w[2];
+            d.y = (dc[0] * c2w[4] + dc[1] * c2w[5]) + dc[2] * c2w[6];
+            d.z = (dc[0] * c2w[8] + dc[1] * c2w[9]) + dc[2] * c2w[10];
+            rays_o[i * 3 + 0] = c2w[3]; rays_o[i * 3 + 1] = c2w[7]; rays_o[i * 3 + 2] = c2w[11];
+            if (ray_diff) {
+                v3_st(rays_d + i * 3, d);
+                float inv = 1.0f / focal;
+                dxdu[i * 3 + 0] = inv * c2w[0]; dxdu[i * 3 + 1] = inv * c2w[4]; dxdu[i * 3 + 2] = inv * c2w[8];
+                dydv[i * 3 + 0] = inv * c2w[1]; dydv[i * 3 + 1] = inv * c2w[5]; dydv[i * 3 + 2] = inv * c2w[9];
+            } else {
+                float n = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z); /* rays_d / torch.norm(rays_d) */
+                v3_st(rays_d + i * 3, v3_make(d.x / n, d.y / n, d.z / n));
+            }
+        }
+}
+
+/* ============================================================================================
+ * a3/a4  shading math (utils/ops.py) and BRDF samplers (model/brdf.py)
+ * ========================================================================================== */
+
+/* utils/ops.py:12-30 get_normal_space -> columns (tangent, bitangent, normal) */
+static inline void normal_space(v3 n, v3 *t, v3 *b) {
+    /* (v1*normal).sum(-1).abs() <= 1e-1, v1=(1,0,0); 1e-1 is compared in float32 */
+    if (fabsf(n.x) <= 0.1f) *t = t_normalize(t_cross(v3_make(1.f, 0.f, 0.f), n));
+    else                    *t = t_normalize(t_cross(v3_make(0.f, 1.f, 0.f), n));
+    *b = t_cross(n, *t);
+}
+ORC_API void orc_get_normal_space(const float *normal, int64_t B, float *out /* B*3*3, [i][j], j=t,b,n */) {
+    for (int64_t i = 0; i < B; ++i) {
+        v3 n = v3_ld(normal + i * 3), t, b;
+        normal_space(n, &t, &b);
+        float *o = out + i * 9;
+        o[0] = t.x; o[1] = b.x; o[2] = n.x;
+        o[3] = t.y; o[4] = b.y; o[5] = n.y;
+        o[6] = t.z; o[7] = b.z; o[8] = n.z;
+    }
+}
+/* utils/ops.py:32-44 angle2xyz */
+static inline v3 angle2xyz(float theta, float phi) {
+    float st = sinf(theta);
+    return t_normalize(v3_make(st * cosf(phi), st * sinf(phi), cosf(theta)));
+}
+/* (wi[:,None] @ Nmat.permute(0,2,1)).squeeze(1): out = l.x*t + l.y*b + l.z*n */
+static inline v3 to_world(v3 l, v3 t, v3 b, v3 n) {
+    return v3_make((l.x * t.x + l.y * b.x) + l.z * n.x, (l.x * t.y + l.y * b.y) + l.z * n.y,
+                   (l.x * t.z + l.y * b.z) + l.z * n.z);
+}
+/* utils/ops.py:85-96 double_sided(V,N) (in place on N) */
+ORC_API void orc_double_sided(const float *V, float *N, int64_t B) {
+    for (int64_t i = 0; i < B; ++i) {
+        v3 v = v3_ld(V + i * 3), n = v3_ld(N + i * 3);
+        if (t_dot(n, v) < 0.f) { N[i * 3] = -n.x; N[i * 3 + 1] = -n.y; N[i * 3 + 2] = -n.z; }
+    }
+}
+
+/* model/brdf.py:20-34 diffuse_sampler */
+static inline v3 diffuse_sampler(float u0, float u1, v3 n) {
+    float theta = asinf(sqrtf(u0));
+    float phi = TWO_PI_F * u1;
+    v3 l = angle2xyz(theta, phi), t, b;
+    normal_space(n, &t, &b);
+    return to_world(l, t, b, n);
+}
+/* model/brdf.py:78-88 BaseBRDF.sample_diffuse */
+ORC_API void orc_sample_diffuse(const float *u2, const float *normal, int64_t B, float *wi, float *pdf, float *w) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < B; ++i) {
+        v3 n = v3_ld(normal + i * 3);
+        v3 d = diffuse_sampler(u2[i * 2], u2[i * 2 + 1], n);
+        v3_st(wi + i * 3, d);
+        if (pdf) pdf[i] = relu(t_dot(n, d)) / PI_F;
+        if (w) { w[i * 3] = 1.f; w[i * 3 + 1] = 1.f; w[i * 3 + 2] = 1.f; }
+    }
+}
+
+/* model/brdf.py:36-59 specular_sampler */
+static inline v3 specular_sampler(float u0, float u1, float rough, v3 wo, v3 n) {
+    float alpha = rough * rough;
+    float c2 = (1.f - u0) / (u0 * (alpha * alpha - 1.f) + 1.f);
+    float theta = acosf(sqrtf(c2));
+    float phi = TWO_PI_F * u1;
+    v3 l = angle2xyz(theta, phi), t, b;
+    normal_space(n, &t, &b);
+    v3 wh = to_world(l, t, b, n);
+    float s = 2.f * t_dot(wo, wh);
+    v3 wi = v3_make(s * wh.x - wo.x, s * wh.y - wo.y, s * wh.z - wo.z);
+    return t_normalize(wi);
+}
+/* utils/ops.py:77-82 D_GGX */
+static inline float D_GGX(float cos_h, float eta) {
+    float alpha = eta * eta, alpha2 = alpha * alpha;
+    float denom = cos_h * cos_h * (alpha2 - 1.0f) + 1.0f;
+    denom = PI_F * denom * denom;
+    return alpha2 / denom;
+}
+/* utils/ops.py:46-63 G1_GGX_Schlick / G_Smith */
+static inline float G1_GGX_Schlick(float NoV, float eta) {
+    float k = eta + 1.f;
+    k = k * k / 8.f;
+    return 1.f / (NoV * (1.f - k) + k);
+}
+static inline float pow5(float x) { return powf(x, 5.f); }
+
+typedef struct { v3 wi; float pdf, g0, g1; } spec_sample;
+/* model/brdf.py:112-136 BaseBRDF.sample_specular */
+static inline spec_sample sample_specular1(float u0, float u1, v3 wo, v3 n, float rough) {
+    spec_sample r;
+    r.wi = specular_sampler(u0, u1, rough, wo, n);
+    v3 h = t_normalize(v3_make(r.wi.x + wo.x, r.wi.y + wo.y, r.wi.z + wo.z));
+    float NoL = relu(t_dot(r.wi, n)), NoV = relu(t_dot(wo, n));
+    float VoH = relu(t_dot(wo, h)), NoH = relu(t_dot(n, h));
+    float D = D_GGX(NoH, rough);
+    float vc = VoH < 1e-4f ? 1e-4f : VoH;
+    r.pdf = D / (4.f * vc) * NoH;
+    float G = G1_GGX_Schlick(NoL, rough) * G1_GGX_Schlick(NoV, rough);
+    float x = pow5(1.f - VoH);
+    float F0 = 1.f - x, F1 = x;
+    float nc = NoH < 1e-4f ? 1e-4f : NoH;
+    float fac = G * VoH * NoL / nc;
+    r.g0 = F0 * fac; r.g1 = F1 * fac;
+    return r;
+}
+ORC_API void orc_sample_specular(const float *u2, const float *wo, const float *normal, float rough, int64_t B,
+                                 float *wi, float *pdf, float *g0, float *g1) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < B; ++i) {
+        spec_sample r = sample_specular1(u2[i * 2], u2[i * 2 + 1], v3_ld(wo + i * 3), v3_ld(normal + i * 3), rough);
+        v3_st(wi + i * 3, r.wi);
+        if (pdf) pdf[i] = r.pdf;
+        if (g0) g0[i] = r.g0;
+        if (g1) g1[i] = r.g1;
+    }
+}
+
+/* utils/ops.py:99-118 lerp_specular: specular (B,R,3), roughness (B) */
+ORC_API void orc_lerp_specular(const float *spec, const float *rough, int64_t B, int R, float *out) {
+    for (int64_t i = 0; i < B; ++i) {
+        /* (roughness-r_min)/(r_max-r_min)*(r_num-1); r_max-r_min is a python double 0.98 cast to f32 */
+        float r = (rough[i] - 0.02f) / (float)(1.0 - 0.02) * (float)(R - 1);
+        int64_t r1 = (int64_t)ceilf(r), r0 = (int64_t)floorf(r);
+        float w = r - (float)r0;
+        for (int c = 0; c < 3; ++c) {
+            float s0 = spec[(i * R + r0) * 3 + c], s1 = spec[(i * R + r1) * 3 + c];
+            out[i * 3 + c] = s0 * (1.f - w) + s1 * w;
+        }
+    }
+}
+
+/* ============================================================================================
+ * a5  VoxelSLF (model/slf.py) and SLFEmitter.eval_emitter (model/emitter.py)
+ * ========================================================================================== */
+typedef struct {
+    int H;
+    const int64_t *inds;   /* H^3, [z][y][x], -1 = empty */
+    const float *radiance; /* kv*3 */
+    int64_t kv;
+    float vmin, den;       /* float32(voxel_min), float32(voxel_max - voxel_min) (python double subtraction) */
+} orc_slf;
+
+ORC_API orc_slf *orc_slf_create(const int64_t *inds, int H, const float *radiance, int64_t kv, double vmin, double vmax) {
+    orc_slf *s = (orc_slf *)calloc(1, sizeof(orc_slf));
+    s->H = H; s->inds = inds; s->radiance = radiance; s->kv = kv;
+    s->vmin = (float)vmin; s->den = (float)(vmax - vmin);
+    return s;
+}
+ORC_API void orc_slf_destroy(orc_slf *s) { free(s); }
+
+/* model/slf.py:41-54 spatial_idx */
+static inline int64_t slf_spatial_idx(const orc_slf *s, v3 p) {
+    float q[3] = {(p.x - s->vmin) / s->den, (p.y - s->vmin) / s->den, (p.z - s->vmin) / s->den};
+    int64_t c[3];
+    for (int k = 0; k < 3; ++k) {
+        float f = q[k] * (float)s->H;
+        int64_t v;
+        /* .long(): truncation toward zero; out-of-range/NaN is UB in C, saturate explicitly
+           (torch on x86 yields INT64_MIN, which the clamp maps to 0) */
+        if (!(f > -9.2e18f)) v = INT64_MIN; else if (f >= 9.2e18f) v = INT64_MIN; else v = (int64_t)f;
+        if (v < 0) v = 0;
+        if (v > s->H - 1) v = s->H - 1;
+        c[k] = v;
+    }
+    return s->inds[(c[2] * s->H + c[1]) * s->H + c[0]];
+}
+ORC_API void orc_slf_spatial_idx(const orc_slf *s, const float *x, int64_t B, int64_t *idx) {
+    for (int64_t i = 0; i < B; ++i) idx[i] = slf_spatial_idx(s, v3_ld(x + i * 3));
+}
+/* model/slf.py:63-70 forward: radiance[idx], zero where idx==-1 */
+static inline v3 slf_forward(const orc_slf *s, v3 p) {
+    int64_t j = slf_spatial_idx(s, p);
+    if (j < 0) return v3_make(0.f, 0.f, 0.f);
+    return v3_ld(s->radiance + j * 3);
+}
+ORC_API void orc_slf_forward(const orc_slf *s, const float *x, int64_t B, float *rgb) {
+    for (int64_t i = 0; i < B; ++i) v3_st(rgb + i * 3, slf_forward(s, v3_ld(x + i * 3)));
+}
+
+typedef struct {
+    int64_t nf, k;
+    const uint8_t *is_emitter; /* nf */
+    int64_t *emitter_idx;      /* nf, -1 = not an emitter (model/emitter.py:160-162) */
+    const float *radiance;     /* rows indexed by emitter ordinal (model/emitter.py:203) */
+    const float *area;         /* k */
+    float emitter_pdf;         /* NF.normalize(ones(k),p=1) = 1/k (model/emitter.py:169) */
+} orc_emitter;
+
+ORC_API orc_emitter *orc_emitter_create(const uint8_t *is_emitter, int64_t nf, const float *radiance, const float *area, int64_t k) {
+    orc_emitter *e = (orc_emitter *)calloc(1, sizeof(orc_emitter));
+    e->nf = nf; e->k = k; e->is_emitter = is_emitter; e->radiance = radiance; e->area = area;
+    e->emitter_idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nf > 0 ? nf : 1));
+    int64_t c = 0;
+    for (int64_t i = 0; i < nf; ++i) e->emitter_idx[i] = is_emitter[i] ? c++ : -1;
+    float s = (float)k; if (s < 1e-12f) s = 1e-12f;
+    e->emitter_pdf = 1.0f / s;
+    return e;
+}
+ORC_API void orc_emitter_destroy(orc_emitter *e) { if (e) { free(e->emitter_idx); free(e); } }
+
+/* model/emitter.py:180-221 eval_emitter for one sample.  rough<0 encodes roughness=None. */
+static inline v3 eval_emitter1(const orc_emitter *e, const orc_slf *s, v3 p, int64_t tri, int has_rough, float rough,
+                               float trace_rough, float *emit_pdf, uint8_t *valid_next) {
+    int vis = tri != -1;
+    v3 Le = v3_make(0.f, 0.f, 0.f);
+    float pdf = 0.f;
+    int64_t ti = tri < 0 ? tri + e->nf : tri; /* python negative index wraps */
+    int is_area = vis && e->is_emitter[ti];
+    if (is_area) {
+        int64_t ei = e->emitter_idx[ti];
+        float a = e->area[ei]; if (a < 1e-12f) a = 1e-12f;
+        pdf = e->emitter_pdf / a;
+        Le = v3_ld(e->radiance + ei * 3);
+    }
+    int vn = (!is_area) && vis;
+    if (has_rough) {
+        int is_diffuse = (!is_area) && vis && (rough > trace_rough);
+        if (is_diffuse) {
+            v3 d = slf_forward(s, p);
+            Le = v3_make(Le.x + d.x, Le.y + d.y, Le.z + d.z);
+            if ((d.x + d.y) + d.z > 0.f) vn = 0;
+        }
+    }
+    if (emit_pdf) *emit_pdf = pdf;
+    if (valid_next) *valid_next = (uint8_t)vn;
+    return Le;
+}
+ORC_API void orc_eval_emitter(const orc_emitter *e, const orc_slf *s, const float *pos, const int64_t *tri,
+                              const float *rough /* nullable */, float trace_rough, int64_t B,
+                              float *Le, float *emit_pdf, uint8_t *valid_next) {
+    for (int64_t i = 0; i < B; ++i) {
+        float pdf; uint8_t vn;
+        v3 l = eval_emitter1(e, s, v3_ld(pos + i * 3), tri[i], rough != NULL, rough ? rough[i] : 0.f, trace_rough, &pdf, &vn);
+        v3_st(Le + i * 3, l);
+        if (emit_pdf) emit_pdf[i] = pdf;
+        if (valid_next) valid_next[i] = vn;
+    }
+}
+
+/* ============================================================================================
+ * a2  ray / triangle-mesh closest hit  (utils/path_tracing.py:17-48; Mitsuba semantics restated)
+ * ========================================================================================== */
+typedef struct {
+    float lo[3], hi[3];
+    int32_t left;   /* internal: index of left child (right = left+1); leaf: -1 */
+    int32_t start, count;
+} orc_node;
+
+typedef struct {
+    int64_t nv, nf;
+    const float *verts;
+    const int32_t *faces;
+    orc_node *nodes; int32_t n_nodes;
+    int32_t *order; /* leaf triangle order */
+} orc_scene;
+
+typedef struct { float t, u, v; int64_t tri; } orc_hit;
+
+/* Moeller-Trumbore, arithmetic contract of the header */
+static inline int tri_test(const orc_scene *sc, int64_t f, v3 o, v3 d, float *t_, float *u_, float *v_) {
+    const int32_t *fi = sc->faces + f * 3;
+    v3 p0 = v3_ld(sc->verts + (int64_t)fi[0] * 3), p1 = v3_ld(sc->verts + (int64_t)fi[1] * 3), p2 = v3_ld(sc->verts + (int64_t)fi[2] * 3);
+    v3 e1 = v3_sub(p1, p0), e2 = v3_sub(p2, p0);
+    v3 pvec = x_cross(d, e2);
+    float det = x_dot(e1, pvec);
+    float inv_det = 1.0f / det;
+    v3 tvec = v3_sub(o, p0);
+    float u = x_dot(tvec, pvec) * inv_det;
+    v3 qvec = x_cross(tvec, e1);
+    float v = x_dot(d, qvec) * inv_det;
+    float t = x_dot(e2, qvec) * inv_det;
+    if (u >= 0.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < INFINITY) { *t_ = t; *u_ = u; *v_ = v; return 1; }
+    return 0;
+}
+static inline void hit_update(orc_hit *h, float t, float u, float v, int64_t f) {
+    if (t < h->t || (t == h->t && f < h->tri)) { h->t = t; h->u = u; h->v = v; h->tri = f; }
+}
+
+static orc_hit intersect_brute(const orc_scene *sc, v3 o, v3 d) {
+    orc_hit h = {INFINITY, 0.f, 0.f, -1};
+    for (int64_t f = 0; f < sc->nf; ++f) {
+        float t, u, v;
+        if (tri_test(sc, f, o, d, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
+    }
+    return h;
+}
+
+/* ---- a small binned-SAH BVH2 (oracle's own; only an accelerator for the brute-force semantics) ---- */
+typedef struct { float lo[3], hi[3], c[3]; } tri_box;
+typedef struct { orc_scene *sc; tri_box *tb; float pad; } build_ctx;
+
+static void box_reset(float *lo, float *hi) { for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; } }
+static void box_grow(float *lo, float *hi, const float *blo, const float *bhi) {
+    for (int k = 0; k < 3; ++k) { if (blo[k] < lo[k]) lo[k] = blo[k]; if (bhi[k] > hi[k]) hi[k] = bhi[k]; }
+}
+static float box_area(const float *lo, const float *hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0) return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+#define ORC_BINS 16
+#define ORC_LEAF 4
+static int32_t build_rec(build_ctx *cx, int32_t start, int32_t count) {
+    orc_scene *sc = cx->sc;
+    int32_t me = sc->n_nodes++;
+    orc_node *nd = &sc->nodes[me];
+    float lo[3], hi[3], clo[3], chi[3];
+    box_reset(lo, hi); box_reset(clo, chi);
+    for (int32_t i = start; i < start + count; ++i) {
+        tri_box *b = &cx->tb[sc->order[i]];
+        box_grow(lo, hi, b->lo, b->hi); box_grow(clo, chi, b->c, b->c);
+    }
+    for (int k = 0; k < 3; ++k) { nd->lo[k] = lo[k] - cx->pad; nd->hi[k] = hi[k] + cx->pad; }
+    nd->left = -1; nd->start = start; nd->count = count;
+    if (count <= ORC_LEAF) return me;
+    /* binned SAH over the widest centroid axis candidates */
+    int best_axis = -1, best_bin = -1; float best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ++ax) {
+        float ext = chi[ax] - clo[ax];
+        if (!(ext > 0.f)) continue;
+        float blo[ORC_BINS][3], bhi[ORC_BINS][3]; int bc[ORC_BINS];
+        for (int b = 0; b < ORC_BINS; ++b) { box_reset(blo[b], bhi[b]); bc[b] = 0; }
+        float sc_ = (float)ORC_BINS / ext;
+        for (int32_t i = start; i < start + count; ++i) {
+            tri_box *t = &cx->tb[sc->order[i]];
+            int b = (int)((t->c[ax] - clo[ax]) * sc_); if (b >= ORC_BINS) b = ORC_BINS - 1; if (b < 0) b = 0;
+            box_grow(blo[b], bhi[b], t->lo, t->hi); bc[b]++;
+        }
+        float ra[ORC_BINS]; int rc[ORC_BINS];
+        float alo[3], ahi[3]; int n = 0; box_reset(alo, ahi);
+        for (int b = ORC_BINS - 1; b > 0; --b) { box_grow(alo, ahi, blo[b], bhi[b]); n += bc[b]; ra[b] = box_area(alo, ahi); rc[b] = n; }
+        box_reset(alo, ahi); n = 0;
+        for (int b = 0; b < ORC_BINS - 1; ++b) {
+            box_grow(alo, ahi, blo[b], bhi[b]); n += bc[b];
+            if (n == 0 || rc[b + 1] == 0) continue;
+            float cost = box_area(alo, ahi) * (float)n + ra[b + 1] * (float)rc[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+        }
+    }
+    int32_t mid;
+    if (best_axis < 0) {
+        mid = start + count / 2; /* all centroids coincide */
+    } else {
+        float ext = chi[best_axis] - clo[best_axis], sc_ = (float)ORC_BINS / ext;
+        int32_t i = start, j = start + count - 1;
+        while (i <= j) {
+            tri_box *t = &cx->tb[sc->order[i]];
+            int b = (int)((t->c[best_axis] - clo[best_axis]) * sc_); if (b >= ORC_BINS) b = ORC_BINS - 1; if (b < 0) b = 0;
+            if (b <= best_bin) ++i; else { int32_t tmp = sc->order[i]; sc->order[i] = sc->order[j]; sc->order[j] = tmp; --j; }
+        }
+        mid = i;
+        if (mid == start || mid == start + count) mid = start + count / 2;
+    }
+    int32_t l = build_rec(cx, start, mid - start);
+    int32_t r = build_rec(cx, mid, start + count - mid);
+    nd = &sc->nodes[me];
+    nd->left = l; nd->start = r; /* for internal nodes `start` holds the right child */
+    nd->count = 0;
+    return me;
+}
+
+ORC_API orc_scene *orc_scene_create(const float *verts, int64_t nv, const int32_t *faces, int64_t nf) {
+    orc_scene *sc = (orc_scene *)calloc(1, sizeof(orc_scene));
+    sc->nv = nv; sc->nf = nf; sc->verts = verts; sc->faces = faces;
+    if (nf == 0) return sc;
+    sc->nodes = (orc_node *)malloc(sizeof(orc_node) * (size_t)(2 * nf));
+    sc->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)nf);
+    tri_box *tb = (tri_box *)malloc(sizeof(tri_box) * (size_t)nf);
+    float glo[3], ghi[3]; box_reset(glo, ghi);
+    for (int64_t f = 0; f < nf; ++f) {
+        sc->order[f] = (int32_t)f;
+        box_reset(tb[f].lo, tb[f].hi);
+        for (int k = 0; k < 3; ++k) {
+            const float *p = verts + (int64_t)faces[f * 3 + k] * 3;
+            box_grow(tb[f].lo, tb[f].hi, p, p);
+        }
+        for (int k = 0; k < 3; ++k) tb[f].c[k] = 0.5f * (tb[f].lo[k] + tb[f].hi[k]);
+        box_grow(glo, ghi, tb[f].lo, tb[f].hi);
+    }
+    float ext = 0.f;
+    for (int k = 0; k < 3; ++k) { float e = ghi[k] - glo[k]; if (e > ext) ext = e; float a = fabsf(glo[k]), b = fabsf(ghi[k]); if (a > ext) ext = a; if (b > ext) ext = b; }
+    build_ctx cx = {sc, tb, 1e-4f * ext + 1e-30f};
+    build_rec(&cx, 0, (int32_t)nf);
+    free(tb);
+    return sc;
+}
+ORC_API void orc_scene_destroy(orc_scene *sc) { if (sc) { free(sc->nodes); free(sc->order); free(sc); } }
+
+static inline int slab(const orc_node *n, v3 o, v3 id, float tbest) {
+    float t0 = (n->lo[0] - o.x) * id.x, t1 = (n->hi[0] - o.x) * id.x;
+    float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
+    t0 = (n->lo[1] - o.y) * id.y; t1 = (n->hi[1] - o.y) * id.y;
+    tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+    t0 = (n->lo[2] - o.z) * id.z; t1 = (n->hi[2] - o.z) * id.z;
+    tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+    /* conservative: a NaN slab (0*inf) is ignored by fmin/fmax; generous relative slack on both ends */
+    return tmax >= 0.f && tmin <= tmax * 1.00001f + 1e-30f && tmin * 0.9999f <= tbest;
+}
+static inline float safe_inv(float d) {
+    if (fabsf(d) < 1e-30f) return d < 0.f || (d == 0.f && signbit(d)) ? -1e30f : 1e30f;
+    return 1.0f / d;
+}
+static orc_hit intersect_bvh(const orc_scene *sc, v3 o, v3 d, int64_t *n_nodes, int64_t *n_tris) {
+    orc_hit h = {INFINITY, 0.f, 0.f, -1};
+    if (sc->nf == 0) return h;
+    v3 id = v3_make(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    int32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const orc_node *n = &sc->nodes[stack[--sp]];
+        if (n_nodes) ++*n_nodes;
+        if (!slab(n, o, id, h.t)) continue;
+        if (n->left < 0) {
+            for (int32_t i = n->start; i < n->start + n->count; ++i) {
+                float t, u, v; int64_t f = sc->order[i];
+                if (n_tris) ++*n_tris;
+                if (tri_test(sc, f, o, d, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
+            }
+        } else { stack[sp++] = n->start; stack[sp++] = n->left; }
+    }
+    return h;
+}
+
+/* Mitsuba Mesh::compute_surface_interaction (restated): p = fma(p0,b0,fma(p1,b1,p2*b2)), b0 = 1-b1-b2 */
+static inline v3 hit_position(const orc_scene *sc, const orc_hit *h) {
+    const int32_t *fi = sc->faces + h->tri * 3;
+    const float *p0 = sc->verts + (int64_t)fi[0] * 3, *p1 = sc->verts + (int64_t)fi[1] * 3, *p2 = sc->verts + (int64_t)fi[2] * 3;
+    float b1 = h->u, b2 = h->v, b0 = (1.f - b1) - b2;
+    return v3_make(fmaf(p0[0], b0, fmaf(p1[0], b1, p2[0] * b2)), fmaf(p0[1], b0, fmaf(p1[1], b1, p2[1] * b2)),
+                   fmaf(p0[2], b0, fmaf(p1[2], b1, p2[2] * b2)));
+}
+static inline v3 hit_normal(const orc_scene *sc, const orc_hit *h) {
+    const int32_t *fi = sc->faces + h->tri * 3;
+    v3 p0 = v3_ld(sc->verts + (int64_t)fi[0] * 3), p1 = v3_ld(sc->verts + (int64_t)fi[1] * 3), p2 = v3_ld(sc->verts + (int64_t)fi[2] * 3);
+    v3 n = x_cross(v3_sub(p1, p0), v3_sub(p2, p0));
+    float len = sqrtf(x_dot(n, n));
+    return v3_make(n.x / len, n.y / len, n.z / len); /* si.n = normalize(cross(dp0,dp1)) */
+}
+
+/* utils/path_tracing.py:17-48 ray_intersect.  mode 0 = brute force, 1 = BVH.
+ * Miss: idx=-1, valid=0, positions/normals/uv = 0 (the reference leaves Mitsuba's values there; callers mask by valid). */
+ORC_API void orc_ray_intersect(const orc_scene *sc, const float *xs, const float *ds, int64_t B, int mode,
+                               float *pos, float *nrm, float *uv, int64_t *idx, uint8_t *valid, float *t_out, int64_t *counters) {
+    int64_t tot_nodes = 0, tot_tris = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : tot_nodes, tot_tris)
+    for (int64_t i = 0; i < B; ++i) {
+        v3 o = v3_ld(xs + i * 3), d = v3_ld(ds + i * 3);
+        int64_t nn = 0, nt = 0;
+        orc_hit h = mode == 0 ? intersect_brute(sc, o, d) : intersect_bvh(sc, o, d, &nn, &nt);
+        tot_nodes += nn; tot_tris += nt;
+        if (h.tri >= 0) {
+            if (pos) v3_st(pos + i * 3, hit_position(sc, &h));
+            if (nrm) {
+                v3 n = t_normalize(hit_normal(sc, &h));         /* NF.normalize(ret.n) */
+                v3 mv = v3_make(-d.x, -d.y, -d.z);               /* double_sided(-ds, normals) */
+                if (t_dot(n, mv) < 0.f) n = v3_make(-n.x, -n.y, -n.z);
+                v3_st(nrm + i * 3, n);
+            }
+            if (uv) { uv[i * 2] = h.u; uv[i * 2 + 1] = h.v; }
+            if (idx) idx[i] = h.tri;
+            if (valid) valid[i] = 1;
+            if (t_out) t_out[i] = h.t;
+        } else {
+            if (pos) { pos[i * 3] = pos[i * 3 + 1] = pos[i * 3 + 2] = 0.f; }
+            if (nrm) { nrm[i * 3] = nrm[i * 3 + 1] = nrm[i * 3 + 2] = 0.f; }
+            if (uv) { uv[i * 2] = uv[i * 2 + 1] = 0.f; }
+            if (idx) idx[i] = -1;
+            if (valid) valid[i] = 0;
+            if (t_out) t_out[i] = INFINITY;
+        }
+    }
+    if (counters) { counters[0] = tot_nodes; counters[1] = tot_tris; }
+}
+
+/* ============================================================================================
+ * Philox4x32-10 counter RNG (perf-mode uniforms; integer work, must match the HIP kernel bit for bit)
+ *   counter = (idx_lo, idx_hi, stream, 0), key = (seed_lo, seed_hi); u0=(c0>>8)*2^-24, u1=(c1>>8)*2^-24
+ * ========================================================================================== */
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+}
+static inline void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float *u0, float *u1) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    *u0 = (float)(c[0] >> 8) * 5.9604644775390625e-08f;
+    *u1 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;
+}
+ORC_API void orc_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream, int64_t n, float *u2) {
+    for (int64_t i = 0; i < n; ++i) philox_u2(seed, idx0 + (uint64_t)i, stream, u2 + i * 2, u2 + i * 2 + 1);
+}
+
+/* ============================================================================================
+ * a6/a7  the bake loop body  (bake_shading.py:108-123 diffuse, :168-188 specular)
+ *
+ * pos/nrm/wo: (P,3) primary-hit records of the valid pixels.  u2: (P*spp,2) explicit uniforms in the
+ * reference's order (row = pixel*spp + sample: concatenation of the per-chunk torch.rand draws), or
+ * NULL -> Philox keyed by (seed, pix_id[p]*spp+s, stream).  rough<0 -> diffuse lobe.
+ * RayEpsilon = 1500 * 2^-24 (mitsuba.math.RayEpsilon for float32).
+ * Outputs: out0 (P,3) = Ld or Ls0, out1 (P,3) = Ls1 (specular only); tri_next (P*spp) optional.
+ * ========================================================================================== */
+static const float RAY_EPS = 1500.0f * 5.9604644775390625e-08f;
+
+ORC_API void orc_bake(const orc_scene *sc, const orc_emitter *em, const orc_slf *slf,
+                      const float *pos, const float *nrm, const float *wo, int64_t P, int spp,
+                      const float *u2, uint64_t seed, uint32_t stream, const int32_t *pix_id, float rough,
+                      float *out0, float *out1, int64_t *tri_next, int64_t *counters) {
+    int64_t tot_nodes = 0, tot_tris = 0;
+    const int specular = rough >= 0.f;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : tot_nodes, tot_tris)
+    for (int64_t p = 0; p < P; ++p) {
+        v3 x = v3_ld(pos + p * 3), n = v3_ld(nrm + p * 3);
+        v3 w = specular ? v3_ld(wo + p * 3) : v3_make(0, 0, 0);
+        double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+        for (int s = 0; s < spp; ++s) {
+            float u0, u1;
+            if (u2) { u0 = u2[(p * spp + s) * 2]; u1 = u2[(p * spp + s) * 2 + 1]; }
+            else philox_u2(seed, (uint64_t)(pix_id ? pix_id[p] : p) * (uint64_t)spp + (uint64_t)s, stream, &u0, &u1);
+            v3 wi; float g0 = 1.f, g1 = 0.f;
+            if (specular) { spec_sample r = sample_specular1(u0, u1, w, n, rough); wi = r.wi; g0 = r.g0; g1 = r.g1; }
+            else wi = diffuse_sampler(u0, u1, n);
+            /* position + RayEpsilon*wi (bake_shading.py:117,180) */
+            v3 o = v3_make(x.x + RAY_EPS * wi.x, x.y + RAY_EPS * wi.y, x.z + RAY_EPS * wi.z);
+            int64_t nn = 0, nt = 0;
+            orc_hit h = intersect_bvh(sc, o, wi, &nn, &nt);
+            tot_nodes += nn; tot_tris += nt;
+            if (tri_next) tri_next[p * spp + s] = h.tri;
+            v3 pn = h.tri >= 0 ? hit_position(sc, &h) : v3_make(0, 0, 0);
+            /* eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0) (bake_shading.py:121-122) */
+            v3 Le = eval_emitter1(em, slf, pn, h.tri, 1, 1.0f, 0.0f, NULL, NULL);
+            if (specular) {
+                a0[0] += (double)(Le.x * g0); a0[1] += (double)(Le.y * g0); a0[2] += (double)(Le.z * g0);
+                a1[0] += (double)(Le.x * g1); a1[1] += (double)(Le.y * g1); a1[2] += (double)(Le.z * g1);
+            } else { a0[0] += Le.x; a0[1] += Le.y; a0[2] += Le.z; }
+        }
+        /* .reshape(b,spp,3).mean(1): summation order of torch's reduction is unspecified; we accumulate in
+           double and round once (differs from any f32 order by <= spp*2^-24 relative) */
+        for (int c = 0; c < 3; ++c) {
+            out0[p * 3 + c] = (float)(a0[c] / (double)spp);
+            if (specular && out1) out1[p * 3 + c] = (float)(a1[c] / (double)spp);
+        }
+    }
+    if (counters) { counters[0] = tot_nodes; counters[1] = tot_tris; }
+}
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORC_API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,211 @@
+"""ctypes binding of ``libiris_oracle.so`` (numpy in / numpy out).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libiris_oracle.so")
+
+RAY_EPSILON = 1500.0 * 2.0 ** -24  # mitsuba.math.RayEpsilon, float32 variants
+
+
+def build(force=False):
+    """Compile the oracle with gcc (Makefile next to this file)."""
+    src = os.path.join(_HERE, "iris_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"] if force else ["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_scene_create.restype = C.c_void_p
+        _lib.orc_slf_create.restype = C.c_void_p
+        _lib.orc_emitter_create.restype = C.c_void_p
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
+# ---------------------------------------------------------------- a1
+def raygen_real(K, c2w, H, W, ray_diff=False):
+    K = _f32(K).reshape(9); c2w = _f32(c2w).reshape(12)
+    n = H * W
+    o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32)
+    dx = np.empty((n, 3), np.float32) if ray_diff else None
+    dy = np.empty((n, 3), np.float32) if ray_diff else None
+    lib().orc_raygen_real(_p(K), _p(c2w), C.c_int(H), C.c_int(W), C.c_int(int(ray_diff)), _p(o), _p(d), _p(dx), _p(dy))
+    return (o, d, dx, dy) if ray_diff else (o, d)
+
+
+def raygen_synthetic(focal, c2w, H, W, ray_diff=False):
+    c2w = _f32(c2w).reshape(12)
+    n = H * W
+    o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32)
+    dx = np.empty((n, 3), np.float32) if ray_diff else None
+    dy = np.empty((n, 3), np.float32) if ray_diff else None
+    lib().orc_raygen_synthetic(C.c_float(focal), _p(c2w), C.c_int(H), C.c_int(W), C.c_int(int(ray_diff)), _p(o), _p(d), _p(dx), _p(dy))
+    return (o, d, dx, dy) if ray_diff else (o, d)
+
+
+# ---------------------------------------------------------------- a3 / a4 / a10
+def get_normal_space(normal):
+    normal = _f32(normal); B = normal.shape[0]
+    out = np.empty((B, 3, 3), np.float32)
+    lib().orc_get_normal_space(_p(normal), C.c_int64(B), _p(out))
+    return out
+
+
+def double_sided(V, N):
+    V = _f32(V); N = _f32(N).copy()
+    lib().orc_double_sided(_p(V), _p(N), C.c_int64(N.shape[0]))
+    return N
+
+
+def sample_diffuse(u2, normal):
+    u2 = _f32(u2); normal = _f32(normal); B = u2.shape[0]
+    wi = np.empty((B, 3), np.float32); pdf = np.empty((B, 1), np.float32); w = np.empty((B, 3), np.float32)
+    lib().orc_sample_diffuse(_p(u2), _p(normal), C.c_int64(B), _p(wi), _p(pdf), _p(w))
+    return wi, pdf, w
+
+
+def sample_specular(u2, wo, normal, roughness):
+    u2 = _f32(u2); wo = _f32(wo); normal = _f32(normal); B = u2.shape[0]
+    wi = np.empty((B, 3), np.float32); pdf = np.empty((B, 1), np.float32)
+    g0 = np.empty((B, 1), np.float32); g1 = np.empty((B, 1), np.float32)
+    lib().orc_sample_specular(_p(u2), _p(wo), _p(normal), C.c_float(np.float32(roughness)), C.c_int64(B), _p(wi), _p(pdf), _p(g0), _p(g1))
+    return wi, pdf, g0, g1
+
+
+def lerp_specular(specular, roughness):
+    specular = _f32(specular); roughness = _f32(roughness).reshape(-1)
+    B, R, _ = specular.shape
+    out = np.empty((B, 3), np.float32)
+    lib().orc_lerp_specular(_p(specular), _p(roughness), C.c_int64(B), C.c_int(R), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- a5
+class VoxelSLF:
+    def __init__(self, inds, radiance, voxel_min, voxel_max):
+        self.inds = np.ascontiguousarray(inds, dtype=np.int64)
+        self.radiance = _f32(radiance).reshape(-1, 3)
+        self.H = int(self.inds.shape[0])
+        self.h = C.c_void_p(lib().orc_slf_create(_p(self.inds), C.c_int(self.H), _p(self.radiance), C.c_int64(self.radiance.shape[0]),
+                                                 C.c_double(float(voxel_min)), C.c_double(float(voxel_max))))
+
+    def spatial_idx(self, x):
+        x = _f32(x); idx = np.empty(x.shape[0], np.int64)
+        lib().orc_slf_spatial_idx(self.h, _p(x), C.c_int64(x.shape[0]), _p(idx))
+        return idx
+
+    def forward(self, x):
+        x = _f32(x); rgb = np.empty((x.shape[0], 3), np.float32)
+        lib().orc_slf_forward(self.h, _p(x), C.c_int64(x.shape[0]), _p(rgb))
+        return rgb
+
+    def __del__(self):
+        try:
+            lib().orc_slf_destroy(self.h)
+        except Exception:
+            pass
+
+
+class SLFEmitter:
+    def __init__(self, is_emitter, emitter_radiance, emitter_area, slf):
+        self.is_emitter = np.ascontiguousarray(is_emitter, dtype=np.uint8)
+        self.radiance = _f32(emitter_radiance).reshape(-1, 3)
+        self.area = _f32(emitter_area).reshape(-1)
+        self.slf = slf
+        self.h = C.c_void_p(lib().orc_emitter_create(_p(self.is_emitter), C.c_int64(self.is_emitter.shape[0]), _p(self.radiance),
+                                                     _p(self.area), C.c_int64(self.area.shape[0])))
+
+    def eval_emitter(self, position, triangle_idx, roughness=None, trace_roughness=0.6):
+        position = _f32(position); tri = np.ascontiguousarray(triangle_idx, dtype=np.int64); B = position.shape[0]
+        r = None if roughness is None else _f32(roughness).reshape(-1)
+        Le = np.empty((B, 3), np.float32); pdf = np.empty((B, 1), np.float32); vn = np.empty(B, np.uint8)
+        lib().orc_eval_emitter(self.h, self.slf.h, _p(position), _p(tri), _p(r), C.c_float(trace_roughness), C.c_int64(B), _p(Le), _p(pdf), _p(vn))
+        return Le, pdf, vn.astype(bool)
+
+    def __del__(self):
+        try:
+            lib().orc_emitter_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- a2
+class Scene:
+    def __init__(self, vertices, faces):
+        self.vertices = _f32(vertices).reshape(-1, 3)
+        self.faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        self.h = C.c_void_p(lib().orc_scene_create(_p(self.vertices), C.c_int64(self.vertices.shape[0]), _p(self.faces), C.c_int64(self.faces.shape[0])))
+
+    def ray_intersect(self, xs, ds, brute=False, counters=False):
+        xs = _f32(xs); ds = _f32(ds); B = xs.shape[0]
+        pos = np.empty((B, 3), np.float32); nrm = np.empty((B, 3), np.float32); uv = np.empty((B, 2), np.float32)
+        idx = np.empty(B, np.int64); valid = np.empty(B, np.uint8); t = np.empty(B, np.float32)
+        cnt = np.zeros(2, np.int64)
+        lib().orc_ray_intersect(self.h, _p(xs), _p(ds), C.c_int64(B), C.c_int(0 if brute else 1), _p(pos), _p(nrm), _p(uv), _p(idx), _p(valid), _p(t), _p(cnt))
+        self.last_t = t
+        if counters:
+            return pos, nrm, uv, idx, valid.astype(bool), cnt
+        return pos, nrm, uv, idx, valid.astype(bool)
+
+    def __del__(self):
+        try:
+            lib().orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+
+def philox_u2(seed, idx0, stream, n):
+    u = np.empty((n, 2), np.float32)
+    lib().orc_philox_u2(C.c_uint64(seed), C.c_uint64(idx0), C.c_uint32(stream), C.c_int64(n), _p(u))
+    return u
+
+
+def bake(scene, emitter, position, normal, spp, wo=None, roughness=None, u2=None, seed=0, stream=0, pix_id=None,
+         want_tri=False, counters=False):
+    """bake_shading.py:108-123 (roughness None -> diffuse) / :168-188 (specular)."""
+    position = _f32(position); normal = _f32(normal); P = position.shape[0]
+    specular = roughness is not None
+    wo_ = _f32(wo) if specular else None
+    u2_ = None if u2 is None else _f32(u2).reshape(P * spp, 2)
+    pid = None if pix_id is None else np.ascontiguousarray(pix_id, dtype=np.int32)
+    out0 = np.empty((P, 3), np.float32); out1 = np.empty((P, 3), np.float32) if specular else None
+    tri = np.empty(P * spp, np.int64) if want_tri else None
+    cnt = np.zeros(2, np.int64)
+    lib().orc_bake(scene.h, emitter.h, emitter.slf.h, _p(position), _p(normal), _p(wo_), C.c_int64(P), C.c_int(spp), _p(u2_),
+                   C.c_uint64(seed), C.c_uint32(stream), _p(pid), C.c_float(np.float32(roughness) if specular else -1.0),
+                   _p(out0), _p(out1), _p(tri), _p(cnt))
+    res = (out0, out1) if specular else (out0,)
+    if want_tri:
+        res = res + (tri,)
+    if counters:
+        res = res + (cnt,)
+    return res
