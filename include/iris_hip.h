@@ -1,0 +1,137 @@
+/*
+ * iris_hip.h -- C ABI of libiris_hip.so, the MI355X (gfx950) implementation of the bake_shading hot path
+ * of facebookresearch/iris.
+ *
+ * The reference has no FFI of its own: the path is ordinary Python calls into Mitsuba/OptiX and ATen.  The
+ * entry points below are therefore exactly the calls a binding of that path needs, one per reference
+ * callable (cited per function as reference-file:line).  See INTEGRATION.md for the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer to contiguous memory owned by the caller (a torch tensor), except
+ *     the inputs of the *_create functions, which are HOST pointers copied during the call.
+ *   - f32 = IEEE binary32; idx arrays are int64 (the reference's torch.long); masks are uint8 (torch.bool).
+ *   - Work is enqueued on the caller's hipStream_t and is asynchronous; nothing here synchronises.
+ *   - Handles are immutable after creation (except iris_emitter_set_radiance) and may be shared by streams.
+ *   - Return value 0 = OK; non-zero = error, message from iris_last_error() (thread local).
+ *   - No C++ exception crosses this boundary.  There is no CPU fallback: without a HIP device every
+ *     compute entry point fails with IRIS_ERR_HIP.
+ */
+#ifndef IRIS_HIP_H
+#define IRIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define IRIS_API __attribute__((visibility("default")))
+#else
+#define IRIS_API
+#endif
+
+typedef void *iris_stream_t; /* hipStream_t */
+
+typedef struct iris_scene iris_scene;     /* triangle mesh + BVH            (mitsuba scene, bake_shading.py:55-61) */
+typedef struct iris_slf iris_slf;         /* VoxelSLF                       (model/slf.py:16-39)                   */
+typedef struct iris_emitter iris_emitter; /* SLFEmitter's emitter tables    (model/emitter.py:134-173)             */
+
+enum { IRIS_OK = 0, IRIS_ERR_ARG = 1, IRIS_ERR_HIP = 2, IRIS_ERR_BUILD = 3 };
+
+#define IRIS_RAY_EPSILON 8.940696716308594e-05f /* mitsuba.math.RayEpsilon (float32) = 1500 * 2^-24 */
+
+/* BVH layouts selectable at scene creation (kernel-choice experiments) */
+enum { IRIS_BVH_DEFAULT = 0, IRIS_BVH4_F32 = 1, IRIS_BVH8_Q8 = 2 };
+
+typedef struct {
+    int64_t n_vertices, n_triangles;
+    int32_t layout;        /* IRIS_BVH4_F32 | IRIS_BVH8_Q8 */
+    int32_t n_nodes;       /* wide nodes */
+    int32_t node_bytes;    /* bytes per node as stored in HBM */
+    int32_t tri_bytes;     /* bytes per leaf-triangle record  */
+    int32_t depth;         /* wide-tree depth */
+    int32_t lds_nodes;     /* nodes of the top of the tree staged in LDS by the traversal kernels */
+    float   sah_cost;      /* SAH cost of the binary tree the wide tree was collapsed from */
+    float   build_seconds;
+} iris_scene_info;
+
+/* ---- handles ----------------------------------------------------------------------------------------- */
+
+/* mitsuba.load_dict({'type':'scene','shape_id':{...}})  (bake_shading.py:55-61).  Host SAH build + upload. */
+IRIS_API int iris_scene_create(const float *verts, int64_t nv, const int32_t *faces, int64_t nf, int device, int layout,
+                      iris_scene **out);
+IRIS_API void iris_scene_destroy(iris_scene *);
+IRIS_API int iris_scene_get_info(const iris_scene *, iris_scene_info *out);
+
+/* VoxelSLF(mask, voxel_min, voxel_max) + load_state_dict (model/slf.py:18-39, model/emitter.py:144-147).
+ * inds: (H,H,H) int64 [z][y][x], -1 = empty; radiance: (kv,3).  voxel_min/max are the python floats stored in
+ * vslf.npz (slf_bake.py:140-145); the denominator is float32(voxel_max - voxel_min) as in torch-CPU. */
+IRIS_API int iris_slf_create(const int64_t *inds, int H, const float *radiance, int64_t kv, double voxel_min, double voxel_max,
+                    int device, iris_slf **out);
+IRIS_API void iris_slf_destroy(iris_slf *);
+
+/* SLFEmitter.__init__ (model/emitter.py:149-173): is_emitter (nf) bool, radiance (n_rad,3) indexed by EMITTER
+ * ORDINAL (model/emitter.py:203), area (k).  emitter_idx / emitter_pdf=1/k are derived here. */
+IRIS_API int iris_emitter_create(const uint8_t *is_emitter, int64_t nf, const float *radiance, int64_t n_rad, const float *area,
+                        int64_t k, int device, iris_emitter **out);
+/* SLFEmitterLearn.radiance is a parameter (model/emitter.py:268): refresh the device copy from a DEVICE pointer. */
+IRIS_API int iris_emitter_set_radiance(iris_emitter *, const float *radiance_dev, int64_t n_rad, iris_stream_t);
+IRIS_API void iris_emitter_destroy(iris_emitter *);
+
+/* ---- a1: ray generation ------------------------------------------------------------------------------ */
+/* get_direction + to_world (utils/dataset/real_ldr.py:49-83; ScanNet++ utils/dataset/scannetpp/dataset.py:202-215).
+ * K (9) and c2w (12) are passed BY VALUE from the host (row-major).  rays_o, rays_d: (H*W,3).  ray_diff: also
+ * dxdu, dydv and un-normalised rays_d. */
+IRIS_API int iris_raygen_real(const float K[9], const float c2w[12], int H, int W, int ray_diff, float *rays_o, float *rays_d,
+                     float *dxdu, float *dydv, iris_stream_t);
+/* get_ray_directions + get_rays (utils/dataset/synthetic_ldr.py:21-57) */
+IRIS_API int iris_raygen_synthetic(float focal, const float c2w[12], int H, int W, int ray_diff, float *rays_o, float *rays_d,
+                          float *dxdu, float *dydv, iris_stream_t);
+
+/* ---- a2: ray_intersect(scene, xs, ds)  (utils/path_tracing.py:17-48) ---------------------------------- */
+/* Any output pointer may be NULL.  Miss: idx=-1, valid=0, pos/nrm/uv=0. */
+IRIS_API int iris_intersect(const iris_scene *, const float *xs, const float *ds, int64_t B, float *pos, float *nrm, float *uv,
+                   int64_t *idx, uint8_t *valid, iris_stream_t);
+
+/* ---- a3/a4: BaseBRDF.sample_diffuse / sample_specular (model/brdf.py:78-88, :112-136) ------------------- */
+IRIS_API int iris_sample_diffuse(const float *u2, const float *normal, int64_t B, float *wi, float *pdf, float *weight,
+                        iris_stream_t);
+IRIS_API int iris_sample_specular(const float *u2, const float *wo, const float *normal, float roughness, int64_t B, float *wi,
+                         float *pdf, float *w0, float *w1, iris_stream_t);
+
+/* ---- a5: VoxelSLF.spatial_idx/forward (model/slf.py:41-70), SLFEmitter.eval_emitter (model/emitter.py:180-221) */
+IRIS_API int iris_slf_lookup(const iris_slf *, const float *x, int64_t B, int64_t *idx /*nullable*/, float *rgb /*nullable*/,
+                    iris_stream_t);
+/* roughness: NULL <=> the reference's roughness=None; otherwise (B) f32. */
+IRIS_API int iris_eval_emitter(const iris_emitter *, const iris_slf *, const float *position, const int64_t *triangle_idx,
+                      const float *roughness, float trace_roughness, int64_t B, float *Le, float *emit_pdf,
+                      uint8_t *valid_next, iris_stream_t);
+
+/* ---- a3..a7 fused: the bake loop body (bake_shading.py:108-123 diffuse, :168-188 specular) -------------- */
+/* pos,nrm[,wo]: (P,3) records of the valid pixels.  u2: (P*spp,2) explicit uniforms in the reference's order
+ * (row = pixel*spp + sample), or NULL -> in-kernel Philox4x32-10 keyed by (seed, pix_id[p]*spp+s, stream);
+ * pix_id (P) int32 nullable (defaults to p) makes the sample set independent of how pixels are sharded.
+ * Ld/Ls0/Ls1: (P,3) = mean over spp of Le, Le*g0, Le*g1.  tri_next (P*spp) int64 nullable debug output. */
+IRIS_API int iris_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
+                      int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,
+                      float *Ld, int64_t *tri_next, iris_stream_t);
+IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
+                       const float *wo, float roughness, int64_t P, int spp, const float *u2, uint64_t seed,
+                       uint32_t stream_id, const int32_t *pix_id, float *Ls0, float *Ls1, int64_t *tri_next,
+                       iris_stream_t);
+
+/* ---- a10: lerp_specular (utils/ops.py:99-118): specular (B,R,3), roughness (B) -> (B,3) ------------------ */
+IRIS_API int iris_lerp_specular(const float *specular, const float *roughness, int64_t B, int R, float *out, iris_stream_t);
+
+/* ---- misc --------------------------------------------------------------------------------------------- */
+/* Philox uniforms exactly as the bake kernels draw them (for tests): u2[i] = U(seed, idx0+i, stream_id). */
+IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream_id, int64_t n, float *u2, iris_stream_t);
+IRIS_API const char *iris_last_error(void);
+IRIS_API const char *iris_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRIS_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libiris_hip.so (include/iris_hip.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiris_hip.so")
+
+BVH_DEFAULT, BVH4_F32, BVH8_Q8 = 0, 1, 2
+
+
+class IrisError(RuntimeError):
+    pass
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_vertices", C.c_int64), ("n_triangles", C.c_int64), ("layout", C.c_int32), ("n_nodes", C.c_int32),
+                ("node_bytes", C.c_int32), ("tri_bytes", C.c_int32), ("depth", C.c_int32), ("lds_nodes", C.c_int32),
+                ("sah_cost", C.c_float), ("build_seconds", C.c_float)]
+
+
+_P, _I64, _I32, _F, _D, _U64, _U32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_uint64, C.c_uint32
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+PROTOTYPES = {
+    "iris_scene_create": [_P, _I64, _P, _I64, _I32, _I32, C.POINTER(_P)],
+    "iris_scene_destroy": [_P],
+    "iris_scene_get_info": [_P, C.POINTER(SceneInfo)],
+    "iris_slf_create": [_P, _I32, _P, _I64, _D, _D, _I32, C.POINTER(_P)],
+    "iris_slf_destroy": [_P],
+    "iris_emitter_create": [_P, _I64, _P, _I64, _P, _I64, _I32, C.POINTER(_P)],
+    "iris_emitter_set_radiance": [_P, _P, _I64, _P],
+    "iris_emitter_destroy": [_P],
+    "iris_raygen_real": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "iris_raygen_synthetic": [_F, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "iris_intersect": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
+    "iris_sample_diffuse": [_P, _P, _I64, _P, _P, _P, _P],
+    "iris_sample_specular": [_P, _P, _P, _F, _I64, _P, _P, _P, _P, _P],
+    "iris_slf_lookup": [_P, _P, _I64, _P, _P, _P],
+    "iris_eval_emitter": [_P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P],
+    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P],
+    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P],
+    "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
+    "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
+    "iris_last_error": [],
+    "iris_version": [],
+}
+_RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when libiris_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IrisError(f"{LIB_PATH} is missing: build it with `make -C iris_amd/csrc` or "
+                            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IrisError(lib().iris_last_error().decode("utf-8", "replace"))
+
+
+def require_gpu(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise IrisError(f"{name}: expected a tensor on a HIP device (got {getattr(t, 'device', type(t))}); "
+                        "iris_amd has no CPU path")
+    if t.dtype != dtype:
+        raise IrisError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_f32(a):
+    import numpy as np
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)

@@ -1,0 +1,103 @@
+"""The bake_shading stage (reference: bake_shading.py) on MI355X.
+
+``bake_diffuse`` / ``bake_specular`` are the reference's two hot loops (bake_shading.py:108-123, :168-188) as ONE
+kernel launch each: uniforms, BRDF sampling, secondary-ray traversal, emitter / SLF lookup, weights and the
+mean over spp never leave the chip.  ``bake_view`` is one iteration of the reference's per-view loops
+(:93-131 and :149-204) and returns the 13 pre-denoise maps; ``main`` keeps the reference's CLI.
+"""
+import math
+import os
+import time
+
+import torch
+
+from . import _lib as L
+from .utils.path_tracing import ray_intersect
+
+SPP_DIFFUSE = 256                                  # bake_shading.py:90
+SPPS_SPECULAR = [64, 128, 128, 128, 128, 128]      # bake_shading.py:143
+N_ROUGHNESS = 6                                    # bake_shading.py:147
+
+
+def roughness_levels():
+    """torch.linspace(0.02,1.0,6) (bake_shading.py:147)"""
+    return torch.linspace(0.02, 1.0, N_ROUGHNESS)
+
+
+def _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri):
+    position = L.require_gpu(position, torch.float32, "position").reshape(-1, 3)
+    normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
+    P = position.shape[0]
+    dev = position.device
+    if u2 is not None:
+        u2 = L.require_gpu(u2, torch.float32, "u2").reshape(-1, 2)
+        if u2.shape[0] != P * spp:
+            raise L.IrisError(f"u2 must have P*spp = {P * spp} rows, got {u2.shape[0]}")
+    if pix_id is not None:
+        pix_id = L.require_gpu(pix_id, torch.int32, "pix_id").reshape(-1)
+        if pix_id.shape[0] != P:
+            raise L.IrisError("pix_id must have one entry per pixel")
+    tri = torch.empty(P * spp, device=dev, dtype=torch.int64) if want_tri else None
+    return position, normal, P, dev, u2, pix_id, tri
+
+
+def bake_diffuse(scene, emitter, position, normal, spp=SPP_DIFFUSE, u2=None, seed=0, stream_id=0, pix_id=None, want_tri=False):
+    """Ld_ of bake_shading.py:108-123 for all P valid pixels: mean over spp of Le along cosine-sampled rays.
+    u2: optional (P*spp,2) uniforms in the reference's order (parity mode); otherwise in-kernel Philox."""
+    position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
+    Ld = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        L.check(L.lib().iris_bake_diffuse(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal),
+                                          P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ld), L.ptr(tri), L.stream()))
+    return (Ld, tri) if want_tri else Ld
+
+
+def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None, seed=0, stream_id=1, pix_id=None, want_tri=False):
+    """Ls0_, Ls1_ of bake_shading.py:168-188 for one roughness level."""
+    position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
+    wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
+    if isinstance(roughness, torch.Tensor):
+        roughness = float(roughness.detach().float().cpu().item())
+    Ls0 = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    Ls1 = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        L.check(L.lib().iris_bake_specular(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo),
+                                           roughness, P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ls0), L.ptr(Ls1),
+                                           L.ptr(tri), L.stream()))
+    return (Ls0, Ls1, tri) if want_tri else (Ls0, Ls1)
+
+
+def primary_hits(scene, xs, ds, pixel_ids=None):
+    """bake_shading.py:98-101 / :154-157: primary closest hit + compaction to the valid pixels.
+    Returns dict(position, normal, wo, pix_id (int32 image-space pixel index), n_pixels)."""
+    positions, normals, _, _, valid = ray_intersect(scene, xs, ds)
+    sel = torch.nonzero(valid, as_tuple=False).reshape(-1)
+    pix = sel if pixel_ids is None else pixel_ids[sel]
+    return {"position": positions[sel], "normal": normals[sel], "wo": -ds.reshape(-1, 3)[sel],
+            "pix_id": pix.to(torch.int32), "sel": sel, "n_pixels": xs.shape[0]}
+
+
+def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=None, seed=0, pixel_ids=None, lobes=None):
+    """One view: the primary pass once (the reference repeats it, :98 and :154), then the diffuse lobe and the six
+    specular roughness levels.  Returns {'diffuse': (N,3), 'specular0': [6x (N,3)], 'specular1': [...], 'n_valid', 'rays'}
+    with N = len(xs) rows in the caller's pixel order (zeros at invalid pixels, bake_shading.py:126-127)."""
+    spps = list(SPPS_SPECULAR if spps_specular is None else spps_specular)
+    g = primary_hits(scene, xs, ds, pixel_ids)
+    N, dev = xs.shape[0], xs.device
+    out = {"n_valid": int(g["sel"].shape[0]), "rays": 0, "specular0": [], "specular1": []}
+    P = out["n_valid"]
+
+    def scatter(v):
+        img = torch.zeros(N, 3, device=dev, dtype=torch.float32)
+        img[g["sel"]] = v
+        return img
+    if lobes is None or 0 in lobes:
+        out["diffuse"] = scatter(bake_diffuse(scene, emitter, g["position"], g["normal"], spp_diffuse, seed=seed, stream_id=0, pix_id=g["pix_id"]))
+        out["rays"] += P * spp_diffuse
+    for r_idx, rough in enumerate(roughness_levels().tolist()):
+        if lobes is not None and (r_idx + 1) not in lobes:
+            continue
+        a, b = bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough, spps[r_idx], seed=seed, stream_id=1 + r_idx, pix_id=g["pix_id"])
+        out["specular0"].append(scatter(a)); out["specular1"].append(scatter(b))
+        out["rays"] += P * spps[r_idx]
+    return out

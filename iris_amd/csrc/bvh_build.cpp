@@ -1,0 +1,214 @@
+// Binned-SAH BVH2 build + collapse to a W-wide tree (host only).  See bvh_build.h.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace iris {
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = kInf; hi[k] = -kInf; } }
+    void grow(const float* a, const float* b) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], a[k]); hi[k] = std::max(hi[k], b[k]); }
+    }
+    void grow(const Box& o) { grow(o.lo, o.hi); }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.f)) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct TriInfo { Box b; float c[3]; };
+
+struct Node2 {
+    Box b;
+    int32_t left = -1, right = -1;  // internal
+    int32_t start = 0, count = 0;   // leaf if count > 0
+};
+
+struct Builder {
+    const TriInfo* tri;
+    int32_t* order;
+    Node2* nodes;
+    std::atomic<int32_t> next{0};
+    int max_leaf;
+
+    int32_t build(int32_t start, int32_t count, int depth) {
+        int32_t me = next.fetch_add(1);
+        Node2& nd = nodes[me];
+        Box b, cb; b.reset(); cb.reset();
+        for (int32_t i = start; i < start + count; ++i) {
+            const TriInfo& t = tri[order[i]];
+            b.grow(t.b); cb.grow(t.c, t.c);
+        }
+        nd.b = b; nd.left = nd.right = -1; nd.start = start; nd.count = count;
+        if (count == 1) return me;
+
+        int best_axis = -1, best_bin = -1;
+        float best_cost = kInf;
+        for (int ax = 0; ax < 3; ++ax) {
+            float ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0.f)) continue;
+            Box bb[kBins]; int bc[kBins];
+            for (int k = 0; k < kBins; ++k) { bb[k].reset(); bc[k] = 0; }
+            const float scale = (float)kBins / ext;
+            for (int32_t i = start; i < start + count; ++i) {
+                const TriInfo& t = tri[order[i]];
+                int k = std::min(kBins - 1, std::max(0, (int)((t.c[ax] - cb.lo[ax]) * scale)));
+                bb[k].grow(t.b); bc[k]++;
+            }
+            float ra[kBins]; int rc[kBins];
+            Box acc; acc.reset(); int n = 0;
+            for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); n += bc[k]; ra[k] = acc.area(); rc[k] = n; }
+            acc.reset(); n = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                acc.grow(bb[k]); n += bc[k];
+                if (n == 0 || rc[k + 1] == 0) continue;
+                float cost = acc.area() * (float)n + ra[k + 1] * (float)rc[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+            }
+        }
+        // SAH termination for small nodes: leaf cost = count * A ; split cost = A (one traversal step) + children
+        if (count <= max_leaf) {
+            float a = b.area();
+            if (best_axis < 0 || (float)count * a <= 1.0f * a + best_cost) return me;
+        }
+        int32_t mid;
+        if (best_axis < 0) {
+            mid = start + count / 2;
+        } else {
+            const float ext = cb.hi[best_axis] - cb.lo[best_axis], scale = (float)kBins / ext;
+            int32_t i = start, j = start + count - 1;
+            while (i <= j) {
+                const TriInfo& t = tri[order[i]];
+                int k = std::min(kBins - 1, std::max(0, (int)((t.c[best_axis] - cb.lo[best_axis]) * scale)));
+                if (k <= best_bin) ++i; else { std::swap(order[i], order[j]); --j; }
+            }
+            mid = i;
+            if (mid == start || mid == start + count) mid = start + count / 2;
+        }
+        int32_t l, r;
+        if (count > (1 << 16) && depth < 4) {
+            int32_t lres = -1;
+            std::thread th([&] { lres = build(start, mid - start, depth + 1); });
+            r = build(mid, start + count - mid, depth + 1);
+            th.join();
+            l = lres;
+        } else {
+            l = build(start, mid - start, depth + 1);
+            r = build(mid, start + count - mid, depth + 1);
+        }
+        Node2& nd2 = nodes[me];
+        nd2.left = l; nd2.right = r; nd2.count = 0;
+        return me;
+    }
+};
+
+float sah_of(const Node2* nodes, int32_t i, float root_area) {
+    const Node2& n = nodes[i];
+    float a = n.b.area() / root_area;
+    if (n.count > 0) return a * (float)n.count;
+    return a + sah_of(nodes, n.left, root_area) + sah_of(nodes, n.right, root_area);
+}
+
+}  // namespace
+
+WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces, int64_t nf, int width, int max_leaf,
+                       float pad_rel) {
+    WideBvh out;
+    out.width = width;
+    for (int k = 0; k < 3; ++k) { out.root_lo[k] = 0.f; out.root_hi[k] = 0.f; }
+    auto empty_node = [&] {
+        WideNode w; w.n = 0;
+        for (int s = 0; s < kMaxWidth; ++s) {
+            for (int k = 0; k < 3; ++k) { w.lo[s][k] = kInf; w.hi[s][k] = -kInf; }
+            w.child[s] = -1; w.leaf_start[s] = 0; w.leaf_count[s] = 0;
+        }
+        return w;
+    };
+    if (nf <= 0) { out.nodes.push_back(empty_node()); out.depth = 1; return out; }
+
+    std::vector<TriInfo> tri((size_t)nf);
+    std::vector<int32_t> order((size_t)nf);
+    Box g; g.reset();
+    for (int64_t f = 0; f < nf; ++f) {
+        order[(size_t)f] = (int32_t)f;
+        TriInfo& t = tri[(size_t)f];
+        t.b.reset();
+        for (int k = 0; k < 3; ++k) { const float* p = verts + (int64_t)faces[f * 3 + k] * 3; t.b.grow(p, p); }
+        for (int k = 0; k < 3; ++k) t.c[k] = 0.5f * (t.b.lo[k] + t.b.hi[k]);
+        g.grow(t.b);
+    }
+    float ext = 0.f;
+    for (int k = 0; k < 3; ++k) ext = std::max({ext, g.hi[k] - g.lo[k], std::fabs(g.lo[k]), std::fabs(g.hi[k])});
+    const float pad = pad_rel * ext + 1e-30f;
+    out.pad = pad;
+
+    std::vector<Node2> nodes((size_t)(2 * nf));
+    Builder bld;
+    bld.tri = tri.data(); bld.order = order.data(); bld.nodes = nodes.data(); bld.max_leaf = max_leaf;
+    bld.build(0, (int32_t)nf, 0);
+    out.sah_cost = sah_of(nodes.data(), 0, std::max(nodes[0].b.area(), 1e-30f));
+    for (int k = 0; k < 3; ++k) { out.root_lo[k] = nodes[0].b.lo[k] - pad; out.root_hi[k] = nodes[0].b.hi[k] + pad; }
+
+    // ---- collapse to `width`-wide nodes, breadth first; internal children of a node get consecutive indices ----
+    out.tri_order.reserve((size_t)nf);
+    struct Item { int32_t n2; int32_t wide; int depth; };
+    std::vector<Item> queue;
+    out.nodes.push_back(empty_node());
+    queue.push_back({0, 0, 1});
+    // a root that is itself a leaf becomes a wide node with one leaf child
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        Item it = queue[qi];
+        out.depth = std::max(out.depth, it.depth);
+        int32_t cand[kMaxWidth]; int nc = 0;
+        const Node2& r = nodes[(size_t)it.n2];
+        if (r.count > 0) { cand[nc++] = it.n2; }
+        else { cand[nc++] = r.left; cand[nc++] = r.right; }
+        while (nc < width) {
+            int pick = -1; float best = -1.f;
+            for (int i = 0; i < nc; ++i) {
+                const Node2& c = nodes[(size_t)cand[i]];
+                if (c.count == 0) { float a = c.b.area(); if (a > best) { best = a; pick = i; } }
+            }
+            if (pick < 0) break;
+            const Node2& c = nodes[(size_t)cand[pick]];
+            cand[pick] = c.left; cand[nc++] = c.right;
+        }
+        WideNode w = empty_node();
+        w.n = nc;
+        // internal children first get consecutive wide indices
+        for (int i = 0; i < nc; ++i) {
+            const Node2& c = nodes[(size_t)cand[i]];
+            for (int k = 0; k < 3; ++k) { w.lo[i][k] = c.b.lo[k] - pad; w.hi[i][k] = c.b.hi[k] + pad; }
+            if (c.count == 0) {
+                w.child[i] = (int32_t)out.nodes.size();
+                out.nodes.push_back(empty_node());
+                queue.push_back({cand[i], w.child[i], it.depth + 1});
+            }
+        }
+        for (int i = 0; i < nc; ++i) {
+            const Node2& c = nodes[(size_t)cand[i]];
+            if (c.count > 0) {
+                w.child[i] = -1;
+                w.leaf_start[i] = (int32_t)out.tri_order.size();
+                w.leaf_count[i] = c.count;
+                for (int32_t j = c.start; j < c.start + c.count; ++j) out.tri_order.push_back(order[(size_t)j]);
+            }
+        }
+        out.nodes[(size_t)it.wide] = w;
+    }
+    return out;
+}
+
+}  // namespace iris

@@ -1,0 +1,181 @@
+// Device-side building blocks of libiris_hip.so (gfx950 only): shading math, RNG, SLF / emitter lookup.
+// Every function cites the reference code it implements.  Compiled with -ffp-contract=off; every fused
+// multiply-add below is an explicit fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace iris {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+// ---- intersection arithmetic contract (must match oracle/iris_oracle.c bit for bit) ----
+__device__ __forceinline__ f3 x_cross(f3 a, f3 b) {
+    return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ float x_dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+
+// ---- torch-order helpers (sum over the last dim in index order, no fma) ----
+__device__ __forceinline__ float t_dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// NF.normalize(v, dim=-1) = v / max(||v||, 1e-12)
+__device__ __forceinline__ f3 t_normalize(f3 a) {
+    float n = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+    n = fmaxf(n, 1e-12f);
+    return mk3(a.x / n, a.y / n, a.z / n);
+}
+__device__ __forceinline__ f3 t_cross(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
+
+constexpr float kPi = 3.14159265358979323846f;     // float32(math.pi)
+constexpr float kTwoPi = 6.28318530717958647692f;  // float32(2*math.pi)
+constexpr float kRayEps = 8.940696716308594e-05f;  // mitsuba.math.RayEpsilon (f32) = 1500*2^-24
+
+// utils/ops.py:12-30 get_normal_space: tangent/bitangent for a unit normal (columns t,b,n).
+__device__ __forceinline__ void normal_space(f3 n, f3& t, f3& b) {
+    // mask = |dot((1,0,0),n)| <= 1e-1 (compared in f32): cross((1,0,0),n) = (0,-nz,ny); else cross((0,1,0),n) = (nz,0,-nx)
+    if (fabsf(n.x) <= 0.1f) t = t_normalize(mk3(0.f, -n.z, n.y));
+    else                    t = t_normalize(mk3(n.z, 0.f, -n.x));
+    b = t_cross(n, t);
+}
+// (w[:,None] @ Nmat.permute(0,2,1)).squeeze(1)
+__device__ __forceinline__ f3 to_world(f3 l, f3 t, f3 b, f3 n) {
+    return mk3((l.x * t.x + l.y * b.x) + l.z * n.x, (l.x * t.y + l.y * b.y) + l.z * n.y, (l.x * t.z + l.y * b.z) + l.z * n.z);
+}
+// utils/ops.py:32-44 angle2xyz given sin(theta), cos(theta) and phi
+__device__ __forceinline__ f3 angle2xyz_sc(float st, float ct, float phi) {
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    return t_normalize(mk3(st * cp, st * sp, ct));
+}
+
+// model/brdf.py:20-34 diffuse_sampler.  theta = asin(sqrt(u0)): sin(theta) = s = fl(sqrt(u0)) and
+// cos(theta) = sqrt((1-s)(1+s)) -- the same function of the ROUNDED s the reference evaluates through
+// asin/sin/cos, without the transcendental round trip (differs by <= ~1e-7 absolute).
+__device__ __forceinline__ f3 diffuse_sampler(float u0, float u1, f3 n, f3 t, f3 b) {
+    float s = sqrtf(u0);
+    float c = sqrtf(fmaxf((1.f - s) * (1.f + s), 0.f));
+    f3 l = angle2xyz_sc(s, c, kTwoPi * u1);
+    return to_world(l, t, b, n);
+}
+
+// model/brdf.py:36-59 specular_sampler.  theta = acos(sqrt(c2)): cos = cs = fl(sqrt(c2)), sin = sqrt((1-cs)(1+cs)).
+__device__ __forceinline__ f3 specular_sampler(float u0, float u1, float rough, f3 wo, f3 n, f3 t, f3 b) {
+    float alpha = rough * rough;
+    float c2 = (1.f - u0) / (u0 * (alpha * alpha - 1.f) + 1.f);
+    float cs = sqrtf(c2);
+    float sn = sqrtf(fmaxf((1.f - cs) * (1.f + cs), 0.f));
+    f3 l = angle2xyz_sc(sn, cs, kTwoPi * u1);
+    f3 wh = to_world(l, t, b, n);
+    float s = 2.f * t_dot(wo, wh);
+    return t_normalize(mk3(s * wh.x - wo.x, s * wh.y - wo.y, s * wh.z - wo.z));
+}
+
+// utils/ops.py:77-82 D_GGX, :46-63 G1_GGX_Schlick/G_Smith, :70-73 fresnelSchlick_sep
+__device__ __forceinline__ float D_GGX(float cos_h, float eta) {
+    float alpha = eta * eta, alpha2 = alpha * alpha;
+    float denom = cos_h * cos_h * (alpha2 - 1.0f) + 1.0f;
+    denom = kPi * denom * denom;
+    return alpha2 / denom;
+}
+__device__ __forceinline__ float G1_GGX_Schlick(float NoV, float eta) {
+    float k = eta + 1.f;
+    k = k * k / 8.f;
+    return 1.f / (NoV * (1.f - k) + k);
+}
+struct SpecW { float pdf, g0, g1; };
+// model/brdf.py:112-136 BaseBRDF.sample_specular, the part after the direction is known
+__device__ __forceinline__ SpecW specular_weights(f3 wi, f3 wo, f3 n, float rough, bool want_pdf) {
+    f3 h = t_normalize(mk3(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z));
+    float NoL = relu(t_dot(wi, n)), NoV = relu(t_dot(wo, n));
+    float VoH = relu(t_dot(wo, h)), NoH = relu(t_dot(n, h));
+    SpecW r;
+    r.pdf = 0.f;
+    if (want_pdf) r.pdf = D_GGX(NoH, rough) / (4.f * fmaxf(VoH, 1e-4f)) * NoH;
+    float G = G1_GGX_Schlick(NoL, rough) * G1_GGX_Schlick(NoV, rough);
+    float x1 = 1.f - VoH, x2 = x1 * x1;
+    float x = x2 * x2 * x1;  // (1-VoH).pow(5)
+    float fac = G * VoH * NoL / fmaxf(NoH, 1e-4f);
+    r.g0 = (1.f - x) * fac;
+    r.g1 = x * fac;
+    return r;
+}
+
+// ---- Philox4x32-10 (perf-mode uniforms): counter=(idx_lo,idx_hi,stream,0) key=(seed_lo,seed_hi) ----
+__device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float& u0, float& u1) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    }
+    u0 = (float)(c0 >> 8) * 5.9604644775390625e-08f;
+    u1 = (float)(c1 >> 8) * 5.9604644775390625e-08f;
+}
+
+// ---- VoxelSLF (model/slf.py) and SLFEmitter tables (model/emitter.py) as laid out in HBM ----
+struct SlfDev {
+    const int32_t* inds;     // H^3 int32 [z][y][x], -1 empty (the reference keeps int64: 128 MiB -> 64 MiB at H=256)
+    const float4* radiance;  // kv rows padded to 16 B: one dwordx4 gather per lookup
+    int H;
+    float vmin, den;         // float32(voxel_min), float32(voxel_max - voxel_min)
+};
+struct EmitDev {
+    const int32_t* emit_ord;  // nf: emitter ordinal or -1   (is_emitter + emitter_idx, model/emitter.py:153-162)
+    const float4* radiance;   // n_rad rows padded to 16 B, indexed by emitter ordinal (model/emitter.py:203)
+    const float* area;        // k
+    int64_t nf;
+    float emitter_pdf;        // 1/k
+};
+
+// model/slf.py:41-54 spatial_idx: ((x-vmin)/(vmax-vmin)*H).long().clamp(0,H-1) -> inds[z,y,x]
+__device__ __forceinline__ int voxel_coord(float p, const SlfDev& s) {
+    float f = (p - s.vmin) / s.den * (float)s.H;
+    int v = (int)f;                    // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+    if (!(f < 9.2e18f)) v = 0;         // torch's int64 cast of +inf/huge/NaN is INT64_MIN -> clamps to 0
+    return min(max(v, 0), s.H - 1);
+}
+__device__ __forceinline__ int slf_index(const SlfDev& s, f3 p) {
+    int cx = voxel_coord(p.x, s), cy = voxel_coord(p.y, s), cz = voxel_coord(p.z, s);
+    return s.inds[((int64_t)cz * s.H + cy) * s.H + cx];
+}
+// model/slf.py:63-70 forward
+__device__ __forceinline__ f3 slf_forward(const SlfDev& s, f3 p) {
+    int j = slf_index(s, p);
+    if (j < 0) return mk3(0.f, 0.f, 0.f);
+    float4 r = s.radiance[j];
+    return mk3(r.x, r.y, r.z);
+}
+// model/emitter.py:180-221 eval_emitter, one sample.  tri = original triangle index or -1.
+__device__ __forceinline__ f3 eval_emitter1(const EmitDev& e, const SlfDev& s, f3 p, int64_t tri, bool has_rough,
+                                            float rough, float trace_rough, float& emit_pdf, bool& valid_next) {
+    bool vis = tri != -1;
+    f3 Le = mk3(0.f, 0.f, 0.f);
+    emit_pdf = 0.f;
+    int ord = -1;
+    if (vis) ord = e.emit_ord[tri < 0 ? tri + e.nf : tri];
+    bool is_area = ord >= 0;
+    if (is_area) {
+        float4 r = e.radiance[ord];
+        Le = mk3(r.x, r.y, r.z);
+        emit_pdf = e.emitter_pdf / fmaxf(e.area[ord], 1e-12f);
+    }
+    valid_next = (!is_area) && vis;
+    if (has_rough && (!is_area) && vis && rough > trace_rough) {
+        f3 d = slf_forward(s, p);
+        Le = mk3(Le.x + d.x, Le.y + d.y, Le.z + d.z);
+        if ((d.x + d.y) + d.z > 0.f) valid_next = false;
+    }
+    return Le;
+}
+
+}  // namespace iris

@@ -1,0 +1,573 @@
+// libiris_hip.so -- kernels and C ABI (include/iris_hip.h).  gfx950 / wave64 only.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/iris_hip.h"
+#include "bvh_build.h"
+#include "iris_device.h"
+#include "iris_trace.h"
+
+using namespace iris;
+
+// ======================================================================================================
+// error plumbing
+// ======================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(IRIS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define API_BEGIN try {
+#define API_END                                                                   \
+    }                                                                             \
+    catch (const std::exception& ex) { return fail(IRIS_ERR_BUILD, ex.what()); }  \
+    catch (...) { return fail(IRIS_ERR_BUILD, "unknown C++ exception"); }
+
+extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
+extern "C" IRIS_API const char* iris_version(void) { return "iris_hip 0.1 (gfx950)"; }
+
+// ======================================================================================================
+// handles
+// ======================================================================================================
+struct iris_scene {
+    int device = 0;
+    SceneDev dev{};
+    void* d_nodes = nullptr;
+    void* d_tris = nullptr;
+    iris_scene_info info{};
+};
+struct iris_slf {
+    int device = 0;
+    SlfDev dev{};
+    void* d_inds = nullptr;
+    void* d_rad = nullptr;
+    int64_t kv = 0;
+};
+struct iris_emitter {
+    int device = 0;
+    EmitDev dev{};
+    void* d_ord = nullptr;
+    void* d_rad = nullptr;
+    void* d_area = nullptr;
+    int64_t n_rad = 0, k = 0;
+};
+
+static int grid_for(int64_t n, int block, int max_blocks) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+static int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int device, int layout,
+                                 iris_scene** out) {
+    API_BEGIN
+    if (!out || nv < 0 || nf < 0 || (nf > 0 && (!verts || !faces))) return fail(IRIS_ERR_ARG, "iris_scene_create: bad arguments");
+    if (nf >= (1 << 28)) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^28 triangles");
+    for (int64_t i = 0; i < nf * 3; ++i)
+        if (faces[i] < 0 || faces[i] >= nv) return fail(IRIS_ERR_ARG, "iris_scene_create: face index out of range");
+    if (layout == IRIS_BVH_DEFAULT) layout = IRIS_BVH4_F32;
+    if (layout != IRIS_BVH4_F32) return fail(IRIS_ERR_ARG, "iris_scene_create: unknown BVH layout");
+    HIP_TRY(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, 4);
+    if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
+
+    // ---- encode nodes (BVH4_F32: 128 B) ----
+    const size_t nn = bvh.nodes.size();
+    std::vector<float> nodes(nn * 32);
+    for (size_t i = 0; i < nn; ++i) {
+        const WideNode& w = bvh.nodes[i];
+        float* p = nodes.data() + i * 32;
+        for (int s = 0; s < 4; ++s) {
+            p[0 + s] = w.lo[s][0]; p[4 + s] = w.hi[s][0];
+            p[8 + s] = w.lo[s][1]; p[12 + s] = w.hi[s][1];
+            p[16 + s] = w.lo[s][2]; p[20 + s] = w.hi[s][2];
+            uint32_t ref = kEmptyRef;
+            if (s < w.n) {
+                if (w.child[s] >= 0) ref = (uint32_t)w.child[s];
+                else ref = kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
+            }
+            std::memcpy(&p[24 + s], &ref, 4);
+            p[28 + s] = 0.f;
+        }
+    }
+    // ---- encode leaf triangles (48 B) ----
+    const size_t nt = bvh.tri_order.size();
+    std::vector<float> tris(std::max<size_t>(nt, 1) * 12, 0.f);
+    for (size_t i = 0; i < nt; ++i) {
+        int32_t f = bvh.tri_order[i];
+        float* p = tris.data() + i * 12;
+        for (int k = 0; k < 3; ++k) {
+            const float* v = verts + (int64_t)faces[(int64_t)f * 3 + k] * 3;
+            p[k * 3 + 0] = v[0]; p[k * 3 + 1] = v[1]; p[k * 3 + 2] = v[2];
+        }
+        std::memcpy(&p[9], &f, 4);
+    }
+    iris_scene* s = new iris_scene();
+    s->device = device;
+    HIP_TRY(hipMalloc(&s->d_nodes, nodes.size() * 4));
+    HIP_TRY(hipMalloc(&s->d_tris, tris.size() * 4));
+    HIP_TRY(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_tris, tris.data(), tris.size() * 4, hipMemcpyHostToDevice));
+    s->dev.nodes = (const float4*)s->d_nodes;
+    s->dev.tris = (const float4*)s->d_tris;
+    s->dev.n_nodes = (int)nn;
+    s->dev.n_tris = (int)nt;
+    s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
+    s->info.node_bytes = 128; s->info.tri_bytes = 48; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
+    s->info.sah_cost = bvh.sah_cost;
+    s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+    *out = s;
+    return IRIS_OK;
+    API_END
+}
+extern "C" IRIS_API void iris_scene_destroy(iris_scene* s) {
+    if (!s) return;
+    (void)hipFree(s->d_nodes); (void)hipFree(s->d_tris);
+    delete s;
+}
+extern "C" IRIS_API int iris_scene_get_info(const iris_scene* s, iris_scene_info* out) {
+    if (!s || !out) return fail(IRIS_ERR_ARG, "iris_scene_get_info: null");
+    *out = s->info;
+    return IRIS_OK;
+}
+
+extern "C" IRIS_API int iris_slf_create(const int64_t* inds, int H, const float* radiance, int64_t kv, double voxel_min, double voxel_max,
+                               int device, iris_slf** out) {
+    API_BEGIN
+    if (!out || !inds || H <= 0 || H > 1024 || kv < 0 || (kv > 0 && !radiance)) return fail(IRIS_ERR_ARG, "iris_slf_create: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)H * H * H;
+    std::vector<int32_t> i32(n);
+    for (size_t i = 0; i < n; ++i) {
+        int64_t v = inds[i];
+        if (v < -1 || v >= kv) return fail(IRIS_ERR_ARG, "iris_slf_create: inds entry out of range");
+        i32[i] = (int32_t)v;
+    }
+    std::vector<float> rad((size_t)std::max<int64_t>(kv, 1) * 4, 0.f);
+    for (int64_t i = 0; i < kv; ++i) { rad[i * 4] = radiance[i * 3]; rad[i * 4 + 1] = radiance[i * 3 + 1]; rad[i * 4 + 2] = radiance[i * 3 + 2]; }
+    iris_slf* s = new iris_slf();
+    s->device = device; s->kv = kv;
+    HIP_TRY(hipMalloc(&s->d_inds, n * 4));
+    HIP_TRY(hipMalloc(&s->d_rad, rad.size() * 4));
+    HIP_TRY(hipMemcpy(s->d_inds, i32.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_rad, rad.data(), rad.size() * 4, hipMemcpyHostToDevice));
+    s->dev.inds = (const int32_t*)s->d_inds; s->dev.radiance = (const float4*)s->d_rad; s->dev.H = H;
+    s->dev.vmin = (float)voxel_min;
+    s->dev.den = (float)(voxel_max - voxel_min);
+    *out = s;
+    return IRIS_OK;
+    API_END
+}
+extern "C" IRIS_API void iris_slf_destroy(iris_slf* s) {
+    if (!s) return;
+    (void)hipFree(s->d_inds); (void)hipFree(s->d_rad);
+    delete s;
+}
+
+extern "C" IRIS_API int iris_emitter_create(const uint8_t* is_emitter, int64_t nf, const float* radiance, int64_t n_rad, const float* area,
+                                   int64_t k, int device, iris_emitter** out) {
+    API_BEGIN
+    if (!out || nf < 0 || k < 0 || n_rad < 0 || (nf > 0 && !is_emitter)) return fail(IRIS_ERR_ARG, "iris_emitter_create: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<int32_t> ord((size_t)std::max<int64_t>(nf, 1), -1);
+    int64_t c = 0;
+    for (int64_t i = 0; i < nf; ++i) ord[(size_t)i] = is_emitter[i] ? (int32_t)c++ : -1;
+    if (c != k) return fail(IRIS_ERR_ARG, "iris_emitter_create: is_emitter.sum() != len(emitter_area)");
+    if (c > n_rad) return fail(IRIS_ERR_ARG, "iris_emitter_create: radiance has fewer rows than emitters");
+    std::vector<float> rad((size_t)std::max<int64_t>(n_rad, 1) * 4, 0.f);
+    for (int64_t i = 0; i < n_rad; ++i) { rad[i * 4] = radiance[i * 3]; rad[i * 4 + 1] = radiance[i * 3 + 1]; rad[i * 4 + 2] = radiance[i * 3 + 2]; }
+    iris_emitter* e = new iris_emitter();
+    e->device = device; e->n_rad = n_rad; e->k = k;
+    HIP_TRY(hipMalloc(&e->d_ord, ord.size() * 4));
+    HIP_TRY(hipMalloc(&e->d_rad, rad.size() * 4));
+    HIP_TRY(hipMalloc(&e->d_area, (size_t)std::max<int64_t>(k, 1) * 4));
+    HIP_TRY(hipMemcpy(e->d_ord, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_rad, rad.data(), rad.size() * 4, hipMemcpyHostToDevice));
+    if (k > 0) HIP_TRY(hipMemcpy(e->d_area, area, (size_t)k * 4, hipMemcpyHostToDevice));
+    e->dev.emit_ord = (const int32_t*)e->d_ord; e->dev.radiance = (const float4*)e->d_rad; e->dev.area = (const float*)e->d_area;
+    e->dev.nf = nf;
+    float kf = (float)k; if (kf < 1e-12f) kf = 1e-12f;  // NF.normalize(ones(k), p=1)
+    e->dev.emitter_pdf = 1.0f / kf;
+    *out = e;
+    return IRIS_OK;
+    API_END
+}
+extern "C" IRIS_API void iris_emitter_destroy(iris_emitter* e) {
+    if (!e) return;
+    (void)hipFree(e->d_ord); (void)hipFree(e->d_rad); (void)hipFree(e->d_area);
+    delete e;
+}
+
+__global__ void pad_rows_kernel(const float* __restrict__ src, float4* __restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = make_float4(src[i * 3], src[i * 3 + 1], src[i * 3 + 2], 0.f);
+}
+extern "C" IRIS_API int iris_emitter_set_radiance(iris_emitter* e, const float* radiance_dev, int64_t n_rad, iris_stream_t stream) {
+    if (!e || !radiance_dev || n_rad != e->n_rad) return fail(IRIS_ERR_ARG, "iris_emitter_set_radiance: bad arguments");
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n_rad, 256, 1024)), dim3(256), 0, (hipStream_t)stream, radiance_dev, (float4*)e->d_rad, n_rad);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+// ======================================================================================================
+// a1 ray generation
+// ======================================================================================================
+struct RaygenArgs { float K[9]; float c2w[12]; float focal; int H, W, ray_diff, synthetic; };
+
+__global__ void raygen_kernel(RaygenArgs a, float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ dxdu,
+                              float* __restrict__ dydv) {
+    const int64_t n = (int64_t)a.H * a.W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
+        float dc0, dc1, ifx, ify;
+        if (a.synthetic) {  // utils/dataset/synthetic_ldr.py:21-34
+            const float hw = (float)((double)a.W / 2.0), hh = (float)((double)a.H / 2.0);
+            dc0 = -(((float)x + 0.5f) - hw) / a.focal;
+            dc1 = -(((float)y + 0.5f) - hh) / a.focal;
+            ifx = ify = 1.0f / a.focal;
+        } else {  // utils/dataset/real_ldr.py:49-61
+            dc0 = ((float)x + 0.5f - a.K[2]) / a.K[0];
+            dc1 = ((float)y + 0.5f - a.K[5]) / a.K[4];
+            ifx = 1.0f / a.K[0]; ify = 1.0f / a.K[4];
+        }
+        f3 d = mk3((dc0 * a.c2w[0] + dc1 * a.c2w[1]) + a.c2w[2], (dc0 * a.c2w[4] + dc1 * a.c2w[5]) + a.c2w[6],
+                   (dc0 * a.c2w[8] + dc1 * a.c2w[9]) + a.c2w[10]);
+        rays_o[i * 3] = a.c2w[3]; rays_o[i * 3 + 1] = a.c2w[7]; rays_o[i * 3 + 2] = a.c2w[11];
+        if (a.ray_diff) {
+            st3(rays_d + i * 3, d);
+            dxdu[i * 3] = ifx * a.c2w[0]; dxdu[i * 3 + 1] = ifx * a.c2w[4]; dxdu[i * 3 + 2] = ifx * a.c2w[8];
+            dydv[i * 3] = ify * a.c2w[1]; dydv[i * 3 + 1] = ify * a.c2w[5]; dydv[i * 3 + 2] = ify * a.c2w[9];
+        } else if (a.synthetic) {
+            float nrm = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);  // rays_d / torch.norm(rays_d)
+            st3(rays_d + i * 3, mk3(d.x / nrm, d.y / nrm, d.z / nrm));
+        } else {
+            st3(rays_d + i * 3, t_normalize(d));
+        }
+    }
+}
+static int raygen_launch(RaygenArgs a, float* o, float* d, float* dx, float* dy, iris_stream_t stream) {
+    if (a.H <= 0 || a.W <= 0 || !o || !d || (a.ray_diff && (!dx || !dy))) return fail(IRIS_ERR_ARG, "iris_raygen: bad arguments");
+    hipLaunchKernelGGL(raygen_kernel, dim3(grid_for((int64_t)a.H * a.W, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, o, d, dx, dy);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_raygen_real(const float K[9], const float c2w[12], int H, int W, int ray_diff, float* rays_o, float* rays_d,
+                                float* dxdu, float* dydv, iris_stream_t stream) {
+    if (!K || !c2w) return fail(IRIS_ERR_ARG, "iris_raygen_real: null K/c2w");
+    RaygenArgs a{};
+    std::memcpy(a.K, K, 36); std::memcpy(a.c2w, c2w, 48);
+    a.H = H; a.W = W; a.ray_diff = ray_diff; a.synthetic = 0; a.focal = 1.f;
+    return raygen_launch(a, rays_o, rays_d, dxdu, dydv, stream);
+}
+extern "C" IRIS_API int iris_raygen_synthetic(float focal, const float c2w[12], int H, int W, int ray_diff, float* rays_o, float* rays_d,
+                                     float* dxdu, float* dydv, iris_stream_t stream) {
+    if (!c2w) return fail(IRIS_ERR_ARG, "iris_raygen_synthetic: null c2w");
+    RaygenArgs a{};
+    std::memcpy(a.c2w, c2w, 48);
+    a.H = H; a.W = W; a.ray_diff = ray_diff; a.synthetic = 1; a.focal = focal;
+    return raygen_launch(a, rays_o, rays_d, dxdu, dydv, stream);
+}
+
+// ======================================================================================================
+// a2 ray_intersect
+// ======================================================================================================
+__global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev sc, const float* __restrict__ xs, const float* __restrict__ ds,
+                                                           int64_t B, float* __restrict__ pos, float* __restrict__ nrm,
+                                                           float* __restrict__ uv, int64_t* __restrict__ idx, uint8_t* __restrict__ valid) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
+        f3 o = ld3(xs + i * 3), d = ld3(ds + i * 3);
+        Hit h = trace_bvh4(sc, o, d, s_stack + threadIdx.x);
+        if (h.slot >= 0) {
+            f3 p0, p1, p2;
+            hit_vertices(sc, h, p0, p1, p2);
+            if (pos) st3(pos + i * 3, hit_position(h, p0, p1, p2));
+            if (nrm) {
+                f3 n = t_normalize(hit_normal(p0, p1, p2));                    // NF.normalize(ret.n)
+                if (t_dot(n, mk3(-d.x, -d.y, -d.z)) < 0.f) n = mk3(-n.x, -n.y, -n.z);  // double_sided(-ds, normals)
+                st3(nrm + i * 3, n);
+            }
+            if (uv) { uv[i * 2] = h.u; uv[i * 2 + 1] = h.v; }
+            if (idx) idx[i] = h.id;
+            if (valid) valid[i] = 1;
+        } else {
+            if (pos) st3(pos + i * 3, mk3(0.f, 0.f, 0.f));
+            if (nrm) st3(nrm + i * 3, mk3(0.f, 0.f, 0.f));
+            if (uv) { uv[i * 2] = 0.f; uv[i * 2 + 1] = 0.f; }
+            if (idx) idx[i] = -1;
+            if (valid) valid[i] = 0;
+        }
+    }
+}
+extern "C" IRIS_API int iris_intersect(const iris_scene* s, const float* xs, const float* ds, int64_t B, float* pos, float* nrm, float* uv,
+                              int64_t* idx, uint8_t* valid, iris_stream_t stream) {
+    if (!s || B < 0 || (B > 0 && (!xs || !ds))) return fail(IRIS_ERR_ARG, "iris_intersect: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(intersect_kernel, dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
+                       pos, nrm, uv, idx, valid);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+// ======================================================================================================
+// a3/a4 samplers, a5 lookups, a10 lerp (unfused entry points of the call surface)
+// ======================================================================================================
+__global__ void sample_diffuse_kernel(const float* __restrict__ u2, const float* __restrict__ normal, int64_t B, float* __restrict__ wi,
+                                      float* __restrict__ pdf, float* __restrict__ weight) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        f3 n = ld3(normal + i * 3), t, b;
+        normal_space(n, t, b);
+        f3 d = diffuse_sampler(u2[i * 2], u2[i * 2 + 1], n, t, b);
+        st3(wi + i * 3, d);
+        if (pdf) pdf[i] = relu(t_dot(n, d)) / kPi;
+        if (weight) st3(weight + i * 3, mk3(1.f, 1.f, 1.f));
+    }
+}
+extern "C" IRIS_API int iris_sample_diffuse(const float* u2, const float* normal, int64_t B, float* wi, float* pdf, float* weight,
+                                   iris_stream_t stream) {
+    if (B < 0 || (B > 0 && (!u2 || !normal || !wi))) return fail(IRIS_ERR_ARG, "iris_sample_diffuse: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(sample_diffuse_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, u2, normal, B, wi, pdf, weight);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+__global__ void sample_specular_kernel(const float* __restrict__ u2, const float* __restrict__ wo, const float* __restrict__ normal,
+                                       float rough, int64_t B, float* __restrict__ wi, float* __restrict__ pdf, float* __restrict__ w0,
+                                       float* __restrict__ w1) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        f3 n = ld3(normal + i * 3), o = ld3(wo + i * 3), t, b;
+        normal_space(n, t, b);
+        f3 d = specular_sampler(u2[i * 2], u2[i * 2 + 1], rough, o, n, t, b);
+        SpecW w = specular_weights(d, o, n, rough, pdf != nullptr);
+        st3(wi + i * 3, d);
+        if (pdf) pdf[i] = w.pdf;
+        if (w0) w0[i] = w.g0;
+        if (w1) w1[i] = w.g1;
+    }
+}
+extern "C" IRIS_API int iris_sample_specular(const float* u2, const float* wo, const float* normal, float roughness, int64_t B, float* wi,
+                                    float* pdf, float* w0, float* w1, iris_stream_t stream) {
+    if (B < 0 || (B > 0 && (!u2 || !wo || !normal || !wi))) return fail(IRIS_ERR_ARG, "iris_sample_specular: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(sample_specular_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, u2, wo, normal, roughness, B,
+                       wi, pdf, w0, w1);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+__global__ void slf_lookup_kernel(SlfDev s, const float* __restrict__ x, int64_t B, int64_t* __restrict__ idx, float* __restrict__ rgb) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        f3 p = ld3(x + i * 3);
+        int j = slf_index(s, p);
+        if (idx) idx[i] = j;
+        if (rgb) {
+            f3 r = mk3(0.f, 0.f, 0.f);
+            if (j >= 0) { float4 q = s.radiance[j]; r = mk3(q.x, q.y, q.z); }
+            st3(rgb + i * 3, r);
+        }
+    }
+}
+extern "C" IRIS_API int iris_slf_lookup(const iris_slf* s, const float* x, int64_t B, int64_t* idx, float* rgb, iris_stream_t stream) {
+    if (!s || B < 0 || (B > 0 && !x)) return fail(IRIS_ERR_ARG, "iris_slf_lookup: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(slf_lookup_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, s->dev, x, B, idx, rgb);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+__global__ void eval_emitter_kernel(EmitDev e, SlfDev s, const float* __restrict__ pos, const int64_t* __restrict__ tri,
+                                    const float* __restrict__ rough, float trace_rough, int64_t B, float* __restrict__ Le,
+                                    float* __restrict__ emit_pdf, uint8_t* __restrict__ valid_next) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        float pdf; bool vn;
+        f3 l = eval_emitter1(e, s, ld3(pos + i * 3), tri[i], rough != nullptr, rough ? rough[i] : 0.f, trace_rough, pdf, vn);
+        st3(Le + i * 3, l);
+        if (emit_pdf) emit_pdf[i] = pdf;
+        if (valid_next) valid_next[i] = vn ? 1 : 0;
+    }
+}
+extern "C" IRIS_API int iris_eval_emitter(const iris_emitter* e, const iris_slf* s, const float* position, const int64_t* triangle_idx,
+                                 const float* roughness, float trace_roughness, int64_t B, float* Le, float* emit_pdf,
+                                 uint8_t* valid_next, iris_stream_t stream) {
+    if (!e || !s || B < 0 || (B > 0 && (!position || !triangle_idx || !Le))) return fail(IRIS_ERR_ARG, "iris_eval_emitter: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(eval_emitter_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, e->dev, s->dev, position,
+                       triangle_idx, roughness, trace_roughness, B, Le, emit_pdf, valid_next);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+__global__ void lerp_specular_kernel(const float* __restrict__ spec, const float* __restrict__ rough, int64_t B, int R, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        float r = (rough[i] - 0.02f) / (float)(1.0 - 0.02) * (float)(R - 1);
+        int r1 = min(max((int)ceilf(r), 0), R - 1), r0 = min(max((int)floorf(r), 0), R - 1);
+        float w = r - floorf(r);
+        for (int c = 0; c < 3; ++c) out[i * 3 + c] = spec[(i * R + r0) * 3 + c] * (1.f - w) + spec[(i * R + r1) * 3 + c] * w;
+    }
+}
+extern "C" IRIS_API int iris_lerp_specular(const float* specular, const float* roughness, int64_t B, int R, float* out, iris_stream_t stream) {
+    if (B < 0 || R < 1 || (B > 0 && (!specular || !roughness || !out))) return fail(IRIS_ERR_ARG, "iris_lerp_specular: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(lerp_specular_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, specular, roughness, B, R, out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+__global__ void philox_kernel(uint64_t seed, uint64_t idx0, uint32_t stream_id, int64_t n, float* __restrict__ u2) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float a, b;
+        philox_u2(seed, idx0 + (uint64_t)i, stream_id, a, b);
+        u2[i * 2] = a; u2[i * 2 + 1] = b;
+    }
+}
+extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream_id, int64_t n, float* u2, iris_stream_t stream) {
+    if (n < 0 || (n > 0 && !u2)) return fail(IRIS_ERR_ARG, "iris_philox_u2: bad arguments");
+    if (n == 0) return IRIS_OK;
+    hipLaunchKernelGGL(philox_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, seed, idx0, stream_id, n, u2);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+// ======================================================================================================
+// a3..a7 fused bake kernel  (bake_shading.py:108-123 / :168-188)
+//
+// Work decomposition: a wave owns `ppw` consecutive pixels per iteration and its 64 lanes are that group's
+// samples (lane -> (pixel, sample)); the spp samples of a pixel are reduced with a fixed xor-butterfly, so the
+// result is deterministic.  Waves stride over the pixel groups (persistent grid = CUs x resident workgroups).
+// Nothing per-sample ever goes to HBM: uniforms (Philox) -> direction -> BVH traversal -> SLF/emitter gather ->
+// weights -> reduction all stay in registers/LDS; per pixel the kernel reads 24-36 B and writes 12-24 B.
+// ======================================================================================================
+struct BakeArgs {
+    SceneDev sc; EmitDev em; SlfDev slf;
+    const float* pos; const float* nrm; const float* wo;
+    const float* u2; const int32_t* pix_id;
+    int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
+    float* out0; float* out1; int64_t* tri_next;
+};
+
+template <bool SPEC>
+__global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const int lane = threadIdx.x & 63;
+    const int spp = a.spp;
+    int lpp, ppw, rounds;  // lanes per pixel, pixels per wave-iteration, rounds of 64 samples
+    if (spp >= 64) { lpp = 64; ppw = 1; rounds = (spp + 63) >> 6; }
+    else if ((spp & (spp - 1)) == 0) { lpp = spp; ppw = 64 / spp; rounds = 1; }
+    else { lpp = 64; ppw = 1; rounds = 1; }
+    const int sub = lane / lpp, sl = lane - sub * lpp;
+    const int64_t n_groups = (a.P + ppw - 1) / ppw;
+    const int64_t wave0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const float inv_spp = 1.0f / (float)spp;
+
+    for (int64_t g = wave0; g < n_groups; g += n_waves) {
+        const int64_t p = g * ppw + sub;
+        const bool pvalid = p < a.P;
+        f3 x = mk3(0.f, 0.f, 0.f), n = mk3(0.f, 0.f, 1.f), w = mk3(0.f, 0.f, 1.f), t, b;
+        uint64_t base = 0;
+        if (pvalid) {
+            x = ld3(a.pos + p * 3); n = ld3(a.nrm + p * 3);
+            if (SPEC) w = ld3(a.wo + p * 3);
+            base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+        }
+        normal_space(n, t, b);
+        float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int r = 0; r < rounds; ++r) {
+            const int s = r * 64 + sl;
+            if (pvalid && s < spp) {
+                float u0, u1;
+                if (a.u2) { const float* up = a.u2 + ((int64_t)p * spp + s) * 2; u0 = up[0]; u1 = up[1]; }
+                else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+                f3 wi; float g0 = 1.f, g1 = 0.f;
+                if (SPEC) {
+                    wi = specular_sampler(u0, u1, a.rough, w, n, t, b);
+                    SpecW sw = specular_weights(wi, w, n, a.rough, false);
+                    g0 = sw.g0; g1 = sw.g1;
+                } else {
+                    wi = diffuse_sampler(u0, u1, n, t, b);
+                }
+                // position + RayEpsilon*wi  (bake_shading.py:117, :180)
+                f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
+                Hit h = trace_bvh4(a.sc, o, wi, s_stack + threadIdx.x);
+                f3 pn = mk3(0.f, 0.f, 0.f);
+                int64_t tri = -1;
+                if (h.slot >= 0) {
+                    f3 p0, p1, p2;
+                    hit_vertices(a.sc, h, p0, p1, p2);
+                    pn = hit_position(h, p0, p1, p2);
+                    tri = h.id;
+                }
+                if (a.tri_next) a.tri_next[(int64_t)p * spp + s] = tri;
+                // eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0)  (bake_shading.py:121-122, :184-185)
+                float epdf; bool vn;
+                f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
+                if (SPEC) {
+                    a0x += Le.x * g0; a0y += Le.y * g0; a0z += Le.z * g0;
+                    a1x += Le.x * g1; a1y += Le.y * g1; a1z += Le.z * g1;
+                } else { a0x += Le.x; a0y += Le.y; a0z += Le.z; }
+            }
+        }
+        // .reshape(b,spp,3).mean(1): fixed butterfly over the lpp lanes of the pixel
+        for (int m = 1; m < lpp; m <<= 1) {
+            a0x += __shfl_xor(a0x, m); a0y += __shfl_xor(a0y, m); a0z += __shfl_xor(a0z, m);
+            if (SPEC) { a1x += __shfl_xor(a1x, m); a1y += __shfl_xor(a1y, m); a1z += __shfl_xor(a1z, m); }
+        }
+        if (pvalid && sl == 0) {
+            st3(a.out0 + p * 3, mk3(a0x * inv_spp, a0y * inv_spp, a0z * inv_spp));
+            if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
+        }
+    }
+}
+
+static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
+                       const float* wo, float rough, int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id,
+                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, iris_stream_t stream) {
+    if (!sc || !em || !slf || P < 0 || spp < 1 || (P > 0 && (!pos || !nrm || !out0 || (spec && (!wo || !out1)))))
+        return fail(IRIS_ERR_ARG, "iris_bake: bad arguments");
+    if (P == 0) return IRIS_OK;
+    BakeArgs a{};
+    a.sc = sc->dev; a.em = em->dev; a.slf = slf->dev;
+    a.pos = pos; a.nrm = nrm; a.wo = wo; a.u2 = u2; a.pix_id = pix_id;
+    a.P = P; a.spp = spp; a.seed = seed; a.stream_id = stream_id; a.rough = rough;
+    a.out0 = out0; a.out1 = out1; a.tri_next = tri_next;
+    const int ppw = (spp < 64 && (spp & (spp - 1)) == 0) ? 64 / spp : 1;
+    const int64_t n_groups = (P + ppw - 1) / ppw;
+    const int grid = grid_for(n_groups * 64, kBlock, num_cus() * 6);
+    if (spec) hipLaunchKernelGGL(bake_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(bake_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_bake_diffuse(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
+                                 int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id, const int32_t* pix_id,
+                                 float* Ld, int64_t* tri_next, iris_stream_t stream) {
+    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, stream);
+}
+extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
+                                  const float* wo, float roughness, int64_t P, int spp, const float* u2, uint64_t seed,
+                                  uint32_t stream_id, const int32_t* pix_id, float* Ls0, float* Ls1, int64_t* tri_next,
+                                  iris_stream_t stream) {
+    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stream);
+}

@@ -1,0 +1,137 @@
+// BVH traversal + Moeller-Trumbore closest hit (replaces utils/path_tracing.py:30-43, the Mitsuba/OptiX call).
+// One ray per lane, per-lane traversal stack in LDS (stack[k*BLOCK + tid] -> conflict-free for ds_read/write_b32).
+#pragma once
+#include "iris_device.h"
+
+namespace iris {
+
+constexpr int kBlock = 256;          // threads per workgroup for every traversal kernel
+constexpr int kStackLds = 24;        // per-lane stack entries kept in LDS (24 KiB per workgroup)
+constexpr int kStackSpill = 72;      // rarely-touched overflow in scratch (correctness only)
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
+
+// Scene as laid out in HBM
+struct SceneDev {
+    const float4* nodes;  // layout-dependent; BVH4_F32: 8 x float4 = 128 B per node, 128-B aligned
+    const float4* tris;   // 3 x float4 = 48 B per leaf triangle: (p0.xyz,p1.x) (p1.yz,p2.xy) (p2.z, id, -, -)
+    int n_nodes;
+    int n_tris;
+};
+
+struct Hit {
+    float t, u, v;
+    int slot;  // index into SceneDev::tris, -1 = miss
+    int id;    // original triangle index
+};
+
+__device__ __forceinline__ float safe_rcp_dir(float d) {
+    // keeps (box - o) * idir finite for axis-parallel rays
+    return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : 1.0f / d;
+}
+
+struct Stack {
+    uint32_t* lds;  // &s_stack[threadIdx.x]
+    uint32_t spill[kStackSpill];
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (sp < kStackLds) lds[sp * kBlock] = v;
+        else spill[min(sp - kStackLds, kStackSpill - 1)] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        --sp;
+        return sp < kStackLds ? lds[sp * kBlock] : spill[min(sp - kStackLds, kStackSpill - 1)];
+    }
+};
+
+// Moeller-Trumbore on leaf record `slot`; arithmetic contract of oracle/iris_oracle.c (explicit fmaf only).
+__device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 d, Hit& h) {
+    const float4* r = sc.tris + (int64_t)slot * 3;
+    float4 a = r[0], b = r[1], c = r[2];
+    f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(a.w, b.x, b.y), p2 = mk3(b.z, b.w, c.x);
+    int id = __float_as_int(c.y);
+    f3 e1 = sub3(p1, p0), e2 = sub3(p2, p0);
+    f3 pvec = x_cross(d, e2);
+    float det = x_dot(e1, pvec);
+    float inv_det = 1.0f / det;
+    f3 tvec = sub3(o, p0);
+    float u = x_dot(tvec, pvec) * inv_det;
+    f3 qvec = x_cross(tvec, e1);
+    float v = x_dot(d, qvec) * inv_det;
+    float t = x_dot(e2, qvec) * inv_det;
+    bool ok = u >= 0.f && v >= 0.f && (u + v) <= 1.f && t >= 0.f && t < INFINITY;
+    // closest hit = lexicographic min of (t, original index)
+    if (ok && (t < h.t || (t == h.t && id < h.id) || h.slot < 0)) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// BVH4_F32 traversal: node = {lox[4],hix[4],loy[4],hiy[4],loz[4],hiz[4],ref[4],pad[4]} (128 B, one L2 line).
+// ref: internal -> node index; leaf -> 0x80000000 | start<<3 | count; unused slot -> inverted box (never hit).
+// -------------------------------------------------------------------------------------------------------
+#define IRIS_CE(ka, ra, kb, rb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
+                                  uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
+
+__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack) {
+    Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
+    const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
+    const float nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
+    const bool px = ix >= 0.f, py = iy >= 0.f, pz = iz >= 0.f;
+    Stack st; st.lds = lds_stack; st.sp = 0;
+    uint32_t cur = 0;  // root
+    while (cur != kEmptyRef) {
+        while (!(cur & kLeafBit)) {
+            const float4* n = sc.nodes + (int64_t)cur * 8;
+            const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
+            const float4 rf = n[6];
+            float k0, k1, k2, k3;
+            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+#define IRIS_SLAB(K, C)                                                                                               \
+    {                                                                                                                 \
+        float tn = fmaxf(fmaxf(fmaf(px ? lox.C : hix.C, ix, nx), fmaf(py ? loy.C : hiy.C, iy, ny)),                   \
+                         fmaxf(fmaf(pz ? loz.C : hiz.C, iz, nz), 0.f));                                               \
+        float tf = fminf(fminf(fmaf(px ? hix.C : lox.C, ix, nx), fmaf(py ? hiy.C : loy.C, iy, ny)),                   \
+                         fminf(fmaf(pz ? hiz.C : loz.C, iz, nz), h.t));                                               \
+        K = tn <= tf ? tn : INFINITY;                                                                                 \
+    }
+            IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
+#undef IRIS_SLAB
+            IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
+            if (k0 < INFINITY) {
+                cur = r0;
+                if (k3 < INFINITY) st.push(r3);
+                if (k2 < INFINITY) st.push(r2);
+                if (k1 < INFINITY) st.push(r1);
+            } else {
+                cur = st.sp > 0 ? st.pop() : kEmptyRef;
+            }
+            if (cur == kEmptyRef) break;
+        }
+        if (cur == kEmptyRef) break;
+        // leaf
+        const int start = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
+        for (int k = 0; k < cnt; ++k) tri_test(sc, start + k, o, d, h);
+        cur = st.sp > 0 ? st.pop() : kEmptyRef;
+    }
+    return h;
+}
+
+// Mitsuba Mesh::compute_surface_interaction restated: p = fma(p0,b0,fma(p1,b1,p2*b2)), b0 = (1-b1)-b2;
+// n = normalize(cross(p1-p0,p2-p0)).
+__device__ __forceinline__ void hit_vertices(const SceneDev& sc, const Hit& h, f3& p0, f3& p1, f3& p2) {
+    const float4* r = sc.tris + (int64_t)h.slot * 3;
+    float4 a = r[0], b = r[1], c = r[2];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(a.w, b.x, b.y); p2 = mk3(b.z, b.w, c.x);
+}
+__device__ __forceinline__ f3 hit_position(const Hit& h, f3 p0, f3 p1, f3 p2) {
+    float b1 = h.u, b2 = h.v, b0 = (1.f - b1) - b2;
+    return mk3(fmaf(p0.x, b0, fmaf(p1.x, b1, p2.x * b2)), fmaf(p0.y, b0, fmaf(p1.y, b1, p2.y * b2)),
+               fmaf(p0.z, b0, fmaf(p1.z, b1, p2.z * b2)));
+}
+__device__ __forceinline__ f3 hit_normal(f3 p0, f3 p1, f3 p2) {
+    f3 n = x_cross(sub3(p1, p0), sub3(p2, p0));
+    float len = sqrtf(x_dot(n, n));
+    return mk3(n.x / len, n.y / len, n.z / len);
+}
+
+}  // namespace iris

@@ -1,0 +1,75 @@
+"""VoxelSLF: sparse voxel radiance cache (reference: model/slf.py:16-70)."""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+class VoxelSLF(nn.Module):
+    """voxel grid based surface light field; same constructor, buffers and state_dict keys as the reference."""
+
+    def __init__(self, mask, voxel_min, voxel_max):
+        super().__init__()
+        H = mask.shape[0]
+        self.H = H
+        self.voxel_min = float(voxel_min)
+        self.voxel_max = float(voxel_max)
+        kk, jj, ii = torch.where(mask)
+        inds = -torch.ones(H, H, H, dtype=torch.long)
+        inds[kk, jj, ii] = torch.arange(len(ii))
+        self.register_buffer("inds", inds)
+        self.register_buffer("radiance", torch.zeros(len(ii), 3))
+        self.register_buffer("count", torch.zeros(len(ii), dtype=torch.long))
+        self._h = None
+        self._h_device = None
+
+    # -- device handle ---------------------------------------------------------------------------------
+    def refresh(self):
+        """Drop the device-side tables; they are rebuilt from the buffers at the next lookup."""
+        h, self._h = self._h, None
+        if h:
+            L.lib().iris_slf_destroy(h)
+
+    def handle(self, device):
+        device = torch.device(device)
+        if self._h is None or self._h_device != device:
+            self.refresh()
+            inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
+            rad = L.host_f32(self.radiance).reshape(-1, 3)
+            h = C.c_void_p()
+            L.check(L.lib().iris_slf_create(inds.ctypes.data_as(C.c_void_p), self.H, rad.ctypes.data_as(C.c_void_p), rad.shape[0],
+                                            self.voxel_min, self.voxel_max, device.index or 0, C.byref(h)))
+            self._h, self._h_device = h, device
+        return self._h
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.refresh()
+        return r
+
+    def __del__(self):
+        try:
+            self.refresh()
+        except Exception:
+            pass
+
+    # -- reference API ---------------------------------------------------------------------------------
+    def _lookup(self, x, want_idx, want_rgb):
+        x = L.require_gpu(x, torch.float32, "x").reshape(-1, 3)
+        B = x.shape[0]
+        idx = torch.empty(B, device=x.device, dtype=torch.int64) if want_idx else None
+        rgb = torch.empty(B, 3, device=x.device, dtype=torch.float32) if want_rgb else None
+        with torch.cuda.device(x.device):
+            L.check(L.lib().iris_slf_lookup(self.handle(x.device), L.ptr(x), B, L.ptr(idx), L.ptr(rgb), L.stream()))
+        return idx, rgb
+
+    def spatial_idx(self, x):
+        """voxel entry index for Bx3 positions, -1 = empty (model/slf.py:41-54)"""
+        return self._lookup(x, True, False)[0]
+
+    def forward(self, x):
+        """query surface light field; zero radiance in empty space (model/slf.py:63-70)"""
+        return {"rgb": self._lookup(x, False, True)[1]}

@@ -1,0 +1,49 @@
+"""CPU-side checks of the C-ABI boundary: the library loads and exports every symbol include/iris_hip.h declares,
+the ctypes prototypes cover exactly that set, and the product never falls back to a CPU path."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def _header_symbols():
+    src = open(os.path.join(REPO, "include", "iris_hip.h")).read()
+    return sorted(set(re.findall(r"IRIS_API[^;(]*?\b(iris_\w+)\s*\(", src)))
+
+
+def test_header_declares_entry_points():
+    syms = _header_symbols()
+    for must in ("iris_scene_create", "iris_intersect", "iris_sample_diffuse", "iris_sample_specular", "iris_eval_emitter",
+                 "iris_bake_diffuse", "iris_bake_specular", "iris_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from iris_amd import _lib as L
+    assert os.path.exists(L.LIB_PATH), "libiris_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (iris_\w+)", out))
+    declared = set(_header_symbols())
+    assert declared <= exported, declared - exported
+    assert exported == declared, exported ^ declared          # nothing undeclared leaks out either
+    assert set(L.PROTOTYPES) == declared
+    lib = L.lib()                                              # dlopen + prototype binding
+    assert lib.iris_version().startswith(b"iris_hip")
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are rejected loudly; nothing in the product imports the oracle."""
+    from iris_amd import _lib as L
+    from iris_amd.model.brdf import BaseBRDF
+    with pytest.raises(L.IrisError):
+        BaseBRDF().sample_diffuse(torch.rand(4, 2), torch.rand(4, 3))
+    for root, _, files in os.walk(os.path.join(REPO, "iris_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
+                assert "iris_oracle" not in txt or "oracle/iris_oracle.c" in txt, f

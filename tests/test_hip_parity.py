@@ -1,0 +1,369 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the Python mirror of the reference's call surface) against
+(1) the golden vectors produced by the reference's own Python and (2) the CPU oracle on seeded inputs.
+
+Bars: bit-exact for integer / index work (triangle ids, voxel ids, masks, Philox) and for the intersection outputs
+(same IEEE operation sequence as the oracle); floating-point sampler outputs within a few 1e-7 absolute (libm vs
+device math); baked maps within 1e-4 relative L2 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+from test_oracle_golden import check_specular_outputs
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from iris_amd import _lib as L
+    L.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ a1
+def test_raygen_real(dev, oracle_mod):
+    from iris_amd.utils.dataset import real_ldr
+    g = golden("raygen_real.npz")
+    H, W = int(g["H"]), int(g["W"])
+    o, d = real_ldr.to_world(real_ldr.get_direction(g["K"], (H, W)), g["c2w"], False, g["K"], device=dev)
+    np.testing.assert_array_equal(N(o), g["rays_o"])
+    np.testing.assert_allclose(N(d), g["rays_d"], atol=ATOL, rtol=0)
+    o, d, dx, dy = real_ldr.to_world(real_ldr.get_direction(g["K"], (H, W)), g["c2w"], True, g["K"], device=dev)
+    np.testing.assert_allclose(N(d), g["rays_d_diff"], atol=ATOL, rtol=1e-6)
+    np.testing.assert_allclose(N(dx), g["dxdu"], atol=ATOL, rtol=1e-6)
+    np.testing.assert_allclose(N(dy), g["dydv"], atol=ATOL, rtol=1e-6)
+    # larger image against the oracle: same IEEE op order -> exact
+    from tools import synth
+    K, c2w = synth.camera(120, 160, 3)
+    o, d = real_ldr.to_world(real_ldr.get_direction(K, (120, 160)), c2w, False, device=dev)
+    oo, od = oracle_mod.raygen_real(K, c2w, 120, 160)
+    np.testing.assert_array_equal(N(o), oo)
+    np.testing.assert_array_equal(N(d), od)
+
+
+def test_raygen_synthetic(dev, oracle_mod):
+    from iris_amd.utils.dataset import synthetic_ldr
+    g = golden("raygen_syn.npz")
+    H, W, focal = int(g["H"]), int(g["W"]), float(g["focal"])
+    o, d = synthetic_ldr.get_rays(synthetic_ldr.get_ray_directions(H, W, focal), g["c2w"], device=dev)
+    np.testing.assert_array_equal(N(o), g["rays_o"])
+    np.testing.assert_allclose(N(d), g["rays_d"], atol=ATOL, rtol=0)
+    o, d, dx, dy = synthetic_ldr.get_rays(synthetic_ldr.get_ray_directions(H, W, focal), g["c2w"], focal=focal, device=dev)
+    np.testing.assert_allclose(N(d), g["rays_d_diff"], atol=ATOL, rtol=1e-6)
+    np.testing.assert_allclose(N(dx), g["dxdu"], atol=ATOL, rtol=1e-6)
+    np.testing.assert_allclose(N(dy), g["dydv"], atol=ATOL, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ a3 / a4 / a10
+def test_sample_diffuse(dev, oracle_mod):
+    from iris_amd.model.brdf import BaseBRDF
+    g = golden("sample_diffuse.npz")
+    wi, pdf, w = BaseBRDF().sample_diffuse(T(g["u2"], dev), T(g["normal"], dev))
+    np.testing.assert_allclose(N(wi), g["wi"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(N(pdf), g["pdf"], atol=ATOL, rtol=0)
+    np.testing.assert_array_equal(N(w), g["weight"])
+    # seeded bulk comparison with the oracle
+    rng = np.random.default_rng(1)
+    n = rng.normal(size=(1 << 18, 3)); n = (n / np.linalg.norm(n, axis=-1, keepdims=True)).astype(np.float32)
+    u = rng.random((1 << 18, 2), dtype=np.float32)
+    wi, pdf, _ = BaseBRDF().sample_diffuse(T(u, dev), T(n, dev))
+    owi, opdf, _ = oracle_mod.sample_diffuse(u, n)
+    np.testing.assert_allclose(N(wi), owi, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(N(pdf), opdf, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("r_idx", range(6))
+def test_sample_specular(dev, r_idx):
+    from iris_amd.model.brdf import BaseBRDF
+    g = golden("sample_specular.npz")
+    r = torch.tensor(g["roughness"][r_idx])
+    out = BaseBRDF().sample_specular(T(g["u2"], dev), T(g["wo"], dev), T(g["normal"], dev), r)
+    check_specular_outputs(r_idx, tuple(N(t) for t in out), g)
+
+
+def test_sample_empty_input(dev):
+    from iris_amd.model.brdf import BaseBRDF
+    wi, pdf, w = BaseBRDF().sample_diffuse(torch.empty(0, 2, device=dev), torch.empty(0, 3, device=dev))
+    assert wi.shape == (0, 3) and pdf.shape == (0, 1) and w.shape == (0, 3)
+
+
+def test_lerp_specular(dev):
+    from iris_amd.utils.ops import lerp_specular
+    g = golden("lerp_specular.npz")
+    out = lerp_specular(T(g["specular"], dev), T(g["roughness"], dev))
+    np.testing.assert_allclose(N(out), g["out"], atol=1e-6, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ a5
+def _slf_from(g, dev, prefix=""):
+    from iris_amd.model.slf import VoxelSLF
+    slf = VoxelSLF(torch.from_numpy(g["mask"]), float(g["voxel_min"]), float(g["voxel_max"]))
+    slf.radiance[:] = torch.from_numpy(g[prefix + "radiance"])
+    assert torch.equal(slf.inds, torch.from_numpy(g["inds"]))
+    return slf
+
+
+def test_voxel_slf(dev):
+    g = golden("slf.npz")
+    slf = _slf_from(g, dev)
+    x = T(g["x"], dev)
+    np.testing.assert_array_equal(N(slf.spatial_idx(x)), g["idx"])
+    np.testing.assert_array_equal(N(slf(x)["rgb"]), g["rgb"])
+
+
+@pytest.mark.parametrize("mode", ["bake", "none", "rough"])
+def test_eval_emitter(dev, mode, tmp_path):
+    from iris_amd.model.emitter import SLFEmitter
+    g = golden("eval_emitter.npz")
+    slf = _slf_from(g, dev, "slf_")
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    K = int(g["is_emitter"].sum())
+    torch.save({"is_emitter": torch.from_numpy(g["is_emitter"]), "emitter_vertices": torch.zeros(K, 3, 3),
+                "emitter_area": torch.from_numpy(g["emitter_area"]), "emitter_normal": torch.zeros(K, 3),
+                "emitter_radiance": torch.from_numpy(g["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(g["mask"]), "voxel_min": float(g["voxel_min"]), "voxel_max": float(g["voxel_max"]),
+                "weight": slf.state_dict()}, sp)
+    em = SLFEmitter(ep, sp)       # the reference's own file formats
+    pos, tri = T(g["position"], dev), T(g["triangle_idx"], dev)
+    ldir = torch.zeros_like(pos)
+    if mode == "bake":
+        Le, pdf, vn = em.eval_emitter(pos, ldir, tri, torch.ones_like(tri)[:, None], trace_roughness=0.0)
+    elif mode == "none":
+        Le, pdf, vn = em.eval_emitter(pos, ldir, tri)
+    else:
+        Le, pdf, vn = em.eval_emitter(pos, ldir, tri, T(g["roughness"], dev), trace_roughness=0.6)
+    np.testing.assert_array_equal(N(Le), g[f"Le_{mode}"])
+    np.testing.assert_allclose(N(pdf), g[f"pdf_{mode}"], rtol=1e-6)
+    np.testing.assert_array_equal(N(vn), g[f"valid_next_{mode}"])
+
+
+def test_philox_matches_oracle(dev, oracle_mod):
+    from iris_amd import _lib as L
+    u = torch.empty(4096, 2, device=dev)
+    L.check(L.lib().iris_philox_u2(0x123456789ABCDEF, (1 << 32) - 100, 3, 4096, L.ptr(u), L.stream()))
+    np.testing.assert_array_equal(N(u), oracle_mod.philox_u2(0x123456789ABCDEF, (1 << 32) - 100, 3, 4096))
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+
+
+# ------------------------------------------------------------------------------------------------ a2
+def _random_soup(rng, n):
+    c = rng.uniform(-1, 1, size=(n, 1, 3))
+    v = (c + rng.normal(scale=0.15, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    return v, np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+
+
+def _check_intersect(dev, oracle_mod, verts, faces, o, d, brute):
+    from iris_amd.utils.path_tracing import Scene, ray_intersect
+    sc = Scene(verts, faces, device=dev)
+    osc = oracle_mod.Scene(verts, faces)
+    p, n, uv, idx, valid = ray_intersect(sc, T(o, dev), T(d, dev))
+    op, on, ouv, oidx, ovalid = osc.ray_intersect(o, d, brute=brute)
+    np.testing.assert_array_equal(N(idx), oidx)        # index work: exact
+    np.testing.assert_array_equal(N(valid), ovalid)
+    np.testing.assert_array_equal(N(uv), ouv)          # same IEEE op sequence: exact
+    np.testing.assert_array_equal(N(p), op)
+    np.testing.assert_array_equal(N(n), on)
+    return ovalid.mean()
+
+
+def test_intersect_random_soup_vs_brute_force(dev, oracle_mod):
+    rng = np.random.default_rng(2)
+    verts, faces = _random_soup(rng, 3000)
+    o = rng.uniform(-1.5, 1.5, size=(20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)); d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    d[:16] = np.eye(3, dtype=np.float32)[np.arange(16) % 3] * np.where(np.arange(16) % 2, -1, 1)[:, None]   # axis-parallel rays
+    hit = _check_intersect(dev, oracle_mod, verts, faces, o, d, brute=True)
+    assert 0.2 < hit < 1.0          # both hits and misses are exercised
+
+
+def test_intersect_box_fixture(dev, oracle_mod):
+    g = golden("bake_box.npz")
+    from iris_amd.utils.path_tracing import Scene, ray_intersect
+    sc = Scene(g["verts"], g["faces"], device=dev)
+    p, n, uv, idx, valid = ray_intersect(sc, T(g["rays_o"], dev), T(g["rays_d"], dev))
+    np.testing.assert_array_equal(N(idx), g["prim_idx"])
+    np.testing.assert_array_equal(N(valid), g["prim_valid"])
+    np.testing.assert_array_equal(N(p), g["prim_position"])
+    np.testing.assert_array_equal(N(n), g["prim_normal"])
+
+
+def test_intersect_degenerate_scenes(dev, oracle_mod):
+    from iris_amd.utils.path_tracing import Scene, ray_intersect
+    o = torch.tensor([[0.2, 0.2, 1.0], [5.0, 5.0, 1.0]], device=dev)
+    d = torch.tensor([[0.0, 0.0, -1.0], [0.0, 0.0, -1.0]], device=dev)
+    one = Scene(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32), device=dev)
+    p, n, uv, idx, valid = ray_intersect(one, o, d)
+    assert N(idx).tolist() == [0, -1] and N(valid).tolist() == [True, False]
+    np.testing.assert_allclose(N(p)[0], [0.2, 0.2, 0.0], atol=1e-7)
+    np.testing.assert_allclose(N(n)[0], [0, 0, 1.0], atol=0)      # face-forwarded against -d
+    empty = Scene(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), device=dev)
+    _, _, _, idx, valid = ray_intersect(empty, o, d)
+    assert N(idx).tolist() == [-1, -1] and not N(valid).any()
+    p, n, uv, idx, valid = ray_intersect(one, torch.empty(0, 3, device=dev), torch.empty(0, 3, device=dev))
+    assert idx.shape == (0,)
+
+
+def test_intersect_room_vs_oracle_bvh(dev, oracle_mod):
+    """200k-triangle room, primary + incoherent rays: HIP BVH == oracle BVH (and both == brute force on a subset)."""
+    from tools import synth
+    r = synth.room(0, 200_000)
+    K, c2w = synth.camera(96, 128, 5)
+    o, d = oracle_mod.raygen_real(K, c2w, 96, 128)
+    rng = np.random.default_rng(3)
+    o2 = (np.array([[2.0, 1.5, 1.3]]) + rng.uniform(-0.3, 0.3, size=(20000, 3))).astype(np.float32)
+    d2 = rng.normal(size=(20000, 3)); d2 = (d2 / np.linalg.norm(d2, axis=-1, keepdims=True)).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    hit = _check_intersect(dev, oracle_mod, r["vertices"], r["faces"], o, d, brute=False)
+    assert hit == 1.0               # closed room: every ray hits
+    osc = oracle_mod.Scene(r["vertices"], r["faces"])
+    sub = rng.choice(len(o), 256, replace=False)
+    _, _, _, idx_b, _ = osc.ray_intersect(o[sub], d[sub], brute=True)
+    _, _, _, idx_a, _ = osc.ray_intersect(o[sub], d[sub], brute=False)
+    np.testing.assert_array_equal(idx_a, idx_b)
+
+
+# ------------------------------------------------------------------------------------------------ fused bake
+def _emitter_files(tmp_path, is_emitter, area, rad, mask, inds, slf_rad, vmin, vmax):
+    from iris_amd.model.slf import VoxelSLF
+    slf = VoxelSLF(torch.from_numpy(mask), vmin, vmax)
+    slf.radiance[:] = torch.from_numpy(slf_rad)
+    assert torch.equal(slf.inds, torch.from_numpy(inds))
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    K = int(is_emitter.sum())
+    torch.save({"is_emitter": torch.from_numpy(is_emitter), "emitter_vertices": torch.zeros(K, 3, 3), "emitter_area": torch.from_numpy(area),
+                "emitter_normal": torch.zeros(K, 3), "emitter_radiance": torch.from_numpy(rad)}, ep)
+    torch.save({"mask": torch.from_numpy(mask), "voxel_min": vmin, "voxel_max": vmax, "weight": slf.state_dict()}, sp)
+    return ep, sp
+
+
+def test_bake_box_golden(dev, tmp_path):
+    """End-to-end against the reference replay (tests/golden/bake_box.npz): explicit uniforms, rel-L2 <= 1e-4."""
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.utils.path_tracing import Scene
+    from iris_amd import bake_shading as bs
+    g = golden("bake_box.npz")
+    ep, sp = _emitter_files(tmp_path, g["is_emitter"], g["emitter_area"], g["emitter_radiance"], g["slf_mask"], g["slf_inds"],
+                            g["slf_radiance"], float(g["voxel_min"]), float(g["voxel_max"]))
+    em = SLFEmitter(ep, sp)
+    sc = Scene(g["verts"], g["faces"], device=dev)
+    v = g["prim_valid"]
+    pos, nrm, wo = T(g["prim_position"][v], dev), T(g["prim_normal"][v], dev), T(-g["rays_d"][v], dev)
+    spp = int(g["spp"])
+    Ld, tri = bs.bake_diffuse(sc, em, pos, nrm, spp, u2=T(g["u2_diffuse"], dev), want_tri=True)
+    assert (N(tri) == g["tri_next_diffuse"]).mean() >= 0.9999
+    assert rel_l2(N(Ld), g["Ld"]) <= 1e-4
+    for r_idx, r in enumerate(g["roughness_level"]):
+        Ls0, Ls1, tri = bs.bake_specular(sc, em, pos, nrm, wo, float(r), spp, u2=T(g[f"u2_spec_{r_idx}"], dev), want_tri=True)
+        assert (N(tri) == g[f"tri_next_spec_{r_idx}"]).mean() >= 0.9995, r_idx
+        assert rel_l2(N(Ls0), g[f"Ls0_{r_idx}"]) <= 1e-4, r_idx
+        assert rel_l2(N(Ls1), g[f"Ls1_{r_idx}"]) <= 1e-4, r_idx
+
+
+@pytest.fixture(scope="module")
+def room_setup(dev, oracle_mod, tmp_path_factory):
+    """cfg-1-like scene: room(seed=0, ~2e5 triangles), H=256 SLF, 64x64 camera."""
+    from tools import synth
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.utils.path_tracing import Scene
+    r = synth.room(0, 200_000)
+    s = synth.slf_for(r["vertices"], r["faces"], 256)
+    e = synth.emitters_for(r["vertices"], r["faces"], r["is_emitter"])
+    tmp = tmp_path_factory.mktemp("room")
+    ep, sp = _emitter_files(tmp, e["is_emitter"], e["emitter_area"], e["emitter_radiance"], s["mask"], s["inds"], s["radiance"],
+                            s["voxel_min"], s["voxel_max"])
+    em = SLFEmitter(ep, sp)
+    sc = Scene(r["vertices"], r["faces"], device=dev)
+    osc = oracle_mod.Scene(r["vertices"], r["faces"])
+    oslf = oracle_mod.VoxelSLF(s["inds"], s["radiance"], s["voxel_min"], s["voxel_max"])
+    oem = oracle_mod.SLFEmitter(e["is_emitter"], e["emitter_radiance"], e["emitter_area"], oslf)
+    K, c2w = synth.camera(64, 64, 2)
+    o, d = oracle_mod.raygen_real(K, c2w, 64, 64)
+    p, n, _, _, valid = osc.ray_intersect(o, d)
+    return {"sc": sc, "em": em, "osc": osc, "oem": oem, "pos": p[valid], "nrm": n[valid], "wo": -d[valid], "room": r, "K": K, "c2w": c2w}
+
+
+@pytest.mark.parametrize("spp", [1, 16, 20, 64, 100, 128])
+def test_bake_diffuse_vs_oracle(dev, oracle_mod, room_setup, spp):
+    """In-kernel Philox path against the oracle's Philox path; ragged / non-power-of-two spp included."""
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    P = 1500 if spp >= 64 else len(s["pos"])
+    pos, nrm = s["pos"][:P], s["nrm"][:P]
+    pix = (np.arange(P, dtype=np.int32) * 7 + 3)
+    Ld, tri = bs.bake_diffuse(s["sc"], s["em"], T(pos, dev), T(nrm, dev), spp, seed=11, stream_id=0, pix_id=T(pix, dev), want_tri=True)
+    oLd, otri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=11, stream=0, pix_id=pix, want_tri=True)
+    assert (N(tri) == otri).mean() >= 0.9995
+    assert (otri >= 0).all()
+    assert rel_l2(N(Ld), oLd) <= 1e-4
+
+
+@pytest.mark.parametrize("r_idx", [0, 2, 5])
+def test_bake_specular_vs_oracle(dev, oracle_mod, room_setup, r_idx):
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    rough = float(torch.linspace(0.02, 1.0, 6)[r_idx])
+    P, spp = 2000, 64
+    pos, nrm, wo = s["pos"][:P], s["nrm"][:P], s["wo"][:P]
+    Ls0, Ls1, tri = bs.bake_specular(s["sc"], s["em"], T(pos, dev), T(nrm, dev), T(wo, dev), rough, spp, seed=5, stream_id=1 + r_idx, want_tri=True)
+    o0, o1, otri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=rough, seed=5, stream=1 + r_idx, want_tri=True)
+    assert (N(tri) == otri).mean() >= 0.999
+    assert rel_l2(N(Ls0), o0) <= 1e-4
+    assert rel_l2(N(Ls1), o1) <= 1e-4
+
+
+def test_bake_properties_full_size(dev, room_setup):
+    """Size-independent properties at a size the oracle would not finish quickly (640x480 x spp 64 = 19.7 M rays):
+    determinism (bit-identical reruns), shard invariance (any pixel subset with its pix_id reproduces the same rows
+    bit for bit), linearity in the radiance tables, closed room => every secondary ray hits, and bounded output."""
+    from tools import synth
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.dataset import real_ldr
+    s = room_setup
+    H, W, spp = 480, 640, 64
+    K, c2w = synth.camera(H, W, 7)
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+    g = bs.primary_hits(s["sc"], xs, ds)
+    assert g["position"].shape[0] == H * W
+    Ld1 = bs.bake_diffuse(s["sc"], s["em"], g["position"], g["normal"], spp, seed=3, pix_id=g["pix_id"])
+    Ld2 = bs.bake_diffuse(s["sc"], s["em"], g["position"], g["normal"], spp, seed=3, pix_id=g["pix_id"])
+    assert torch.equal(Ld1, Ld2)
+    assert torch.isfinite(Ld1).all() and float(Ld1.min()) >= 0.0 and float(Ld1.max()) <= 10.0 + 1e-3
+    sel = torch.arange(5, H * W, 13, device=dev)
+    Lsub = bs.bake_diffuse(s["sc"], s["em"], g["position"][sel], g["normal"][sel], spp, seed=3, pix_id=g["pix_id"][sel])
+    assert torch.equal(Lsub, Ld1[sel])
+    # linearity: scaling both radiance tables by 2 scales the map by exactly 2 (power-of-two scaling is exact in f32)
+    em = s["em"]
+    em.radiance.mul_(2.0); em.slf.radiance.mul_(2.0); em.refresh(); em.slf.refresh()
+    try:
+        Ld3 = bs.bake_diffuse(s["sc"], em, g["position"], g["normal"], spp, seed=3, pix_id=g["pix_id"])
+    finally:
+        em.radiance.mul_(0.5); em.slf.radiance.mul_(0.5); em.refresh(); em.slf.refresh()
+    assert torch.equal(Ld3, Ld1 * 2.0)
+
+
+def test_bake_view_layout(dev, room_setup):
+    """bake_view returns the 13 maps of one view in image order with zeros at invalid pixels."""
+    from tools import synth
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.dataset import real_ldr
+    s = room_setup
+    H, W = 24, 32
+    K, c2w = synth.camera(H, W, 1)
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+    out = bs.bake_view(s["sc"], s["em"], xs, ds, spp_diffuse=16, spps_specular=[16] * 6, seed=1)
+    assert out["diffuse"].shape == (H * W, 3) and len(out["specular0"]) == 6 and len(out["specular1"]) == 6
+    assert out["rays"] == out["n_valid"] * 16 * 7
+    assert all(torch.isfinite(t).all() for t in [out["diffuse"]] + out["specular0"] + out["specular1"])
