@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- bake_shading throughput on MI355X (BASELINE.json metric: Mrays/s = shading samples / s).
+
+A "step" is one full bake of one 1920x1080 view of the synthetic ScanNet++-like room (SURVEY.md section 8(d) cfg 3/4):
+primary pass + diffuse lobe + 6 specular roughness levels, every lobe at SPP=128, all inputs resident in HBM, uniforms
+from the in-kernel Philox stream, plus (N>1) the single all_gather of the 13 maps.  One ray = one (pixel, sample, lobe)
+secondary ray traced AND shaded.  N>1 shards the pixels of the SAME view over the ranks (strong scaling).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused specular bake kernel): achieved =
+algorithmic bytes per launch (bytes/ray from traversal counters of an instrumented launch of the same kernel on a
+pixel sample) / mean launch time measured with HIP events on the launch stream.  `cpu_baseline` is the
+CPU oracle (a port of the same algorithm, oracle/) timed on a bounded pixel sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(args, dev):
+    from tools import synth
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.utils.path_tracing import Scene
+    import tempfile
+    room = synth.room(args.scene_seed, args.tris)
+    slf = synth.slf_for(room["vertices"], room["faces"], args.slf_res)
+    emi = synth.emitters_for(room["vertices"], room["faces"], room["is_emitter"])
+    tmp = tempfile.mkdtemp(prefix="iris_bench_")
+    ep, sp = os.path.join(tmp, "emitter.pth"), os.path.join(tmp, "vslf.npz")
+    from iris_amd.model.slf import VoxelSLF
+    v = VoxelSLF(torch.from_numpy(slf["mask"]), slf["voxel_min"], slf["voxel_max"])
+    v.radiance[:] = torch.from_numpy(slf["radiance"])
+    torch.save({"is_emitter": torch.from_numpy(emi["is_emitter"]), "emitter_vertices": torch.from_numpy(emi["emitter_vertices"]),
+                "emitter_area": torch.from_numpy(emi["emitter_area"]), "emitter_normal": torch.zeros(len(emi["emitter_area"]), 3),
+                "emitter_radiance": torch.from_numpy(emi["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(slf["mask"]), "voxel_min": slf["voxel_min"], "voxel_max": slf["voxel_max"], "weight": v.state_dict()}, sp)
+    emitter = SLFEmitter(ep, sp)          # the reference's own file formats
+    scene = Scene(room["vertices"], room["faces"], device=dev, layout=args.layout)
+    emitter.handle(dev); emitter.slf.handle(dev)
+    return room, slf, emi, scene, emitter
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--scene-seed", type=int, default=1)
+    ap.add_argument("--slf-res", type=int, default=256)
+    ap.add_argument("--layout", type=int, default=0)
+    ap.add_argument("--lobes", type=str, default="0,1,2,3,4,5,6", help="0 = diffuse, 1..6 = specular roughness levels")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from iris_amd import bake_shading as bs
+    from iris_amd import sharding as sh
+    from iris_amd.utils.dataset import real_ldr
+    from tools import synth
+
+    lobes = sorted(int(x) for x in args.lobes.split(","))
+    H, W, spp = args.height, args.width, args.spp
+    room, slf_np, emi_np, scene, emitter = build_workload(args, dev)
+    info = scene.info()
+    K, c2w = synth.camera(H, W, 0)
+    pix_local = sh.local_pixel_ids(H, W, world, rank, device=dev)
+    rough = bs.roughness_levels().tolist()
+    n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
+
+    ev_pairs = []   # (start,end) HIP events around every specular bake launch, on the launch stream
+
+    def step(record_events=False):
+        """One view: rays -> primary hits (this rank's stripes) -> 7 fused lobe kernels -> scatter -> one all_gather."""
+        xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+        xs, ds = xs[pix_local], ds[pix_local]
+        g = bs.primary_hits(scene, xs, ds, pixel_ids=pix_local)
+        P = g["position"].shape[0]
+        maps = torch.zeros(n_maps, pix_local.numel(), 3, device=dev)
+        m = 0
+        rays = 0
+        if 0 in lobes:
+            maps[m, g["sel"]] = bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"]); m += 1
+            rays += P * spp
+        for l in lobes:
+            if l == 0:
+                continue
+            if record_events:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()      # torch's current stream == the stream the kernel is launched on (L.stream())
+            a, b = bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"])
+            if record_events:
+                e1.record(); ev_pairs.append((e0, e1, P * spp))
+            maps[m, g["sel"]] = a; maps[m + 1, g["sel"]] = b; m += 2
+            rays += P * spp
+        full = sh.gather_maps(maps, H, W, world, rank)
+        return rays, full
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    rays_local = 0
+    for _ in range(args.steps):
+        r, full = step(record_events=True)
+        rays_local += r
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    rays_t = torch.tensor([rays_local], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+    dt = float(t.item()); rays_total = float(rays_t.item())
+    value = rays_total / dt / 1e6
+
+    result = {
+        "metric": "bake_shading throughput (shading samples/s: secondary rays traced and shaded)", "value": round(value, 2), "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"bake_shading one {W}x{H} view, SPP={spp} per lobe, lobes={lobes} (0=diffuse,1-6=specular), synthetic room "
+                               f"seed={args.scene_seed} {info['n_triangles']} triangles, SLF H={args.slf_res}, Philox uniforms",
+                   "pixels_per_view": H * W, "rays_per_step": int(rays_total / max(args.steps, 1)), "sharding": f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 all_gather",
+                   "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"]}},
+    }
+
+    if rank == 0 and not args.no_roofline and any(l > 0 for l in lobes) and ev_pairs:
+        # ---- roofline of the dominant kernel (bake_kernel<SPEC>) ----
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in ev_pairs]
+        rays_per_launch = float(np.mean([n for _, _, n in ev_pairs]))
+        avg_ms = float(np.mean(ms))
+        # algorithmic bytes/ray: instrumented launch of the same kernel on every 16th pixel, all six roughness levels
+        xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+        g = bs.primary_hits(scene, xs[pix_local], ds[pix_local], pixel_ids=pix_local)
+        sel = torch.arange(0, g["position"].shape[0], 16, device=dev)
+        stats = torch.zeros(8, device=dev, dtype=torch.int64)
+        for l in range(1, 7):
+            bs.bake_specular(scene, emitter, g["position"][sel], g["normal"][sel], g["wo"][sel], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"][sel], stats=stats)
+        torch.cuda.synchronize()
+        st = stats.cpu().numpy().astype(np.float64)
+        n_node, n_tri = st[1] / st[0], st[2] / st[0]
+        # fixed per-ray traffic: SLF index 4 B + radiance row 16 B + emitter ordinal 4 B + hit-triangle refetch 48 B
+        # per-pixel traffic amortised over spp: pos+nrm+wo 36 B + pix_id 4 B in, 24 B out
+        bytes_per_ray = n_node * info["node_bytes"] + n_tri * info["tri_bytes"] + (4 + 16 + 4 + info["tri_bytes"]) + (36 + 4 + 24) / spp
+        achieved = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                              "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
+                              "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3), "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
+                              "launch_ms": round(avg_ms, 3), "launch_ms_by_roughness_level": [round(float(np.mean(ms[i::len([l for l in lobes if l > 0])])), 2) for i in range(len([l for l in lobes if l > 0]))],
+                              "launches": len(ms), "mrays_per_s_kernel": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1)}
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----
+        import oracle
+        oracle.build()
+        threads = os.cpu_count() or 1
+        oracle.set_num_threads(threads)
+        osc = oracle.Scene(room["vertices"], room["faces"])
+        oslf = oracle.VoxelSLF(slf_np["inds"], slf_np["radiance"], slf_np["voxel_min"], slf_np["voxel_max"])
+        oem = oracle.SLFEmitter(emi_np["is_emitter"], emi_np["emitter_radiance"], emi_np["emitter_area"], oslf)
+        xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+        g = bs.primary_hits(scene, xs, ds)
+        pos, nrm, wo = g["position"].cpu().numpy(), g["normal"].cpu().numpy(), g["wo"].cpu().numpy()
+
+        def cpu_run(n_px):
+            sel = np.linspace(0, len(pos) - 1, n_px).astype(np.int64)
+            t0 = time.perf_counter()
+            n = 0
+            for l in lobes:
+                if l == 0:
+                    oracle.bake(osc, oem, pos[sel], nrm[sel], spp, seed=0, stream=0, pix_id=sel.astype(np.int32))
+                else:
+                    oracle.bake(osc, oem, pos[sel], nrm[sel], spp, wo=wo[sel], roughness=rough[l - 1], seed=0, stream=l, pix_id=sel.astype(np.int32))
+                n += n_px * spp
+            return n, time.perf_counter() - t0
+        n, dtc = cpu_run(max(threads * 4, 256))                # calibration
+        rate = n / dtc
+        n_px = int(min(len(pos), max(threads * 4, rate * args.cpu_seconds / (spp * len(lobes)))))
+        n, dtc = cpu_run(n_px)
+        result["cpu_baseline"] = {"value": round(n / dtc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                                  "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, OpenMP"}
+        result["gpu_over_cpu"] = round(value / (n / dtc / 1e6), 1)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

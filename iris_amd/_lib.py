@@ -39,8 +39,8 @@ PROTOTYPES = {
     "iris_sample_specular": [_P, _P, _P, _F, _I64, _P, _P, _P, _P, _P],
     "iris_slf_lookup": [_P, _P, _I64, _P, _P, _P],
     "iris_eval_emitter": [_P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P],
-    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P],
-    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P],
+    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P],
+    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
     "iris_last_error": [],

@@ -465,9 +465,10 @@ struct BakeArgs {
     const float* u2; const int32_t* pix_id;
     int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
     float* out0; float* out1; int64_t* tri_next;
+    unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
 };
 
-template <bool SPEC>
+template <bool SPEC, bool COUNT>
 __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     const int lane = threadIdx.x & 63;
@@ -481,6 +482,8 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
     const int64_t wave0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
     const float inv_spp = 1.0f / (float)spp;
+    TraceStats ts;
+    uint32_t n_rays = 0;
 
     for (int64_t g = wave0; g < n_groups; g += n_waves) {
         const int64_t p = g * ppw + sub;
@@ -510,7 +513,8 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
                 }
                 // position + RayEpsilon*wi  (bake_shading.py:117, :180)
                 f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-                Hit h = trace_bvh4(a.sc, o, wi, s_stack + threadIdx.x);
+                Hit h = trace_bvh4<COUNT>(a.sc, o, wi, s_stack + threadIdx.x, &ts);
+                if (COUNT) n_rays++;
                 f3 pn = mk3(0.f, 0.f, 0.f);
                 int64_t tri = -1;
                 if (h.slot >= 0) {
@@ -539,11 +543,19 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
             if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
         }
     }
+    if (COUNT) {
+        uint32_t v[5] = {n_rays, ts.nodes, ts.tris, ts.node_iters, ts.leaf_iters};
+        for (int k = 0; k < 5; ++k) {
+            uint32_t x = v[k];
+            for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+            if (lane == 0) atomicAdd(a.stats + k, (unsigned long long)x);
+        }
+    }
 }
 
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                        const float* wo, float rough, int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id,
-                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, iris_stream_t stream) {
+                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, uint64_t* stats, iris_stream_t stream) {
     if (!sc || !em || !slf || P < 0 || spp < 1 || (P > 0 && (!pos || !nrm || !out0 || (spec && (!wo || !out1)))))
         return fail(IRIS_ERR_ARG, "iris_bake: bad arguments");
     if (P == 0) return IRIS_OK;
@@ -551,23 +563,28 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     a.sc = sc->dev; a.em = em->dev; a.slf = slf->dev;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.u2 = u2; a.pix_id = pix_id;
     a.P = P; a.spp = spp; a.seed = seed; a.stream_id = stream_id; a.rough = rough;
-    a.out0 = out0; a.out1 = out1; a.tri_next = tri_next;
+    a.out0 = out0; a.out1 = out1; a.tri_next = tri_next; a.stats = (unsigned long long*)stats;
     const int ppw = (spp < 64 && (spp & (spp - 1)) == 0) ? 64 / spp : 1;
     const int64_t n_groups = (P + ppw - 1) / ppw;
     const int grid = grid_for(n_groups * 64, kBlock, num_cus() * 6);
-    if (spec) hipLaunchKernelGGL(bake_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(bake_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    if (stats) {
+        if (spec) hipLaunchKernelGGL((bake_kernel<true, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((bake_kernel<false, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    } else {
+        if (spec) hipLaunchKernelGGL((bake_kernel<true, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((bake_kernel<false, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
 extern "C" IRIS_API int iris_bake_diffuse(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                                  int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id, const int32_t* pix_id,
-                                 float* Ld, int64_t* tri_next, iris_stream_t stream) {
-    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, stream);
+                                 float* Ld, int64_t* tri_next, uint64_t* stats, iris_stream_t stream) {
+    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, stats, stream);
 }
 extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                                   const float* wo, float roughness, int64_t P, int spp, const float* u2, uint64_t seed,
                                   uint32_t stream_id, const int32_t* pix_id, float* Ls0, float* Ls1, int64_t* tri_next,
-                                  iris_stream_t stream) {
-    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stream);
+                                  uint64_t* stats, iris_stream_t stream) {
+    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stats, stream);
 }

@@ -72,7 +72,20 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 
 #define IRIS_CE(ka, ra, kb, rb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                   uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
 
-__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack) {
+// Traversal statistics (instrumented builds only): per-lane counts, reduced by the caller.
+struct TraceStats {
+    uint32_t nodes = 0;       // node visits of this lane
+    uint32_t tris = 0;        // triangle tests of this lane
+    uint32_t node_iters = 0;  // wave-level executions of the node step (counted by the first active lane)
+    uint32_t leaf_iters = 0;  // wave-level executions of the triangle test
+};
+__device__ __forceinline__ bool first_active_lane() {
+    unsigned long long m = __ballot(1);
+    return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
+}
+
+template <bool COUNT = false>
+__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr) {
     Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
     const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
     const float nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
@@ -81,6 +94,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
     uint32_t cur = 0;  // root
     while (cur != kEmptyRef) {
         while (!(cur & kLeafBit)) {
+            if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
             const float4* n = sc.nodes + (int64_t)cur * 8;
             const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
             const float4 rf = n[6];
@@ -110,7 +124,10 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
         if (cur == kEmptyRef) break;
         // leaf
         const int start = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
-        for (int k = 0; k < cnt; ++k) tri_test(sc, start + k, o, d, h);
+        for (int k = 0; k < cnt; ++k) {
+            if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
+            tri_test(sc, start + k, o, d, h);
+        }
         cur = st.sp > 0 ? st.pop() : kEmptyRef;
     }
     return h;

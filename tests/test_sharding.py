@@ -1,0 +1,71 @@
+"""world_size-2 gloo test of the N>1 path (CPU): stripes partition the image, and bake-per-rank + one all_gather
+reproduces the single-process maps bit for bit.  The per-rank 'bake' here is the CPU oracle keyed by image pixel ids,
+exactly how the GPU path keys its Philox streams (tests may use the oracle; the product never does)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, golden
+
+
+def test_stripes_partition_image():
+    from iris_amd import sharding as sh
+    for H, W, world in [(1080, 1920, 8), (480, 640, 4), (33, 7, 2), (5, 3, 8), (16, 4, 1)]:
+        seen = torch.cat([sh.local_pixel_ids(H, W, world, r) for r in range(world)])
+        assert seen.numel() == H * W and torch.equal(seen.sort().values, torch.arange(H * W))
+        counts = [sh.local_pixel_ids(H, W, world, r).numel() for r in range(world)]
+        assert max(counts) == sh.max_local_pixels(H, W, world)
+        if H >= world * sh.STRIPE_ROWS * 4:
+            assert max(counts) - min(counts) <= sh.STRIPE_ROWS * W       # balanced to within one stripe
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from iris_amd import sharding as sh
+        g = golden("bake_box.npz")
+        H, W, spp = int(g["H"]), int(g["W"]), 4
+        sc = oracle.Scene(g["verts"], g["faces"])
+        slf = oracle.VoxelSLF(g["slf_inds"], g["slf_radiance"], float(g["voxel_min"]), float(g["voxel_max"]))
+        em = oracle.SLFEmitter(g["is_emitter"], g["emitter_radiance"], g["emitter_area"], slf)
+        ids = sh.local_pixel_ids(H, W, world, rank, stripe=4).numpy()
+        pos, nrm, wo = g["prim_position"][ids], g["prim_normal"][ids], -g["rays_d"][ids]
+        (Ld,) = oracle.bake(sc, em, pos, nrm, spp, seed=9, stream=0, pix_id=ids.astype(np.int32))
+        a, b = oracle.bake(sc, em, pos, nrm, spp, wo=wo, roughness=0.412, seed=9, stream=3, pix_id=ids.astype(np.int32))
+        local = torch.from_numpy(np.stack([Ld, a, b]))
+        full = sh.gather_maps(local, H, W, world, rank, stripe=4)
+        if rank == 0:
+            q.put(full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_bake_equals_single_process(oracle_mod):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = golden("bake_box.npz")
+    sc = oracle_mod.Scene(g["verts"], g["faces"])
+    slf = oracle_mod.VoxelSLF(g["slf_inds"], g["slf_radiance"], float(g["voxel_min"]), float(g["voxel_max"]))
+    em = oracle_mod.SLFEmitter(g["is_emitter"], g["emitter_radiance"], g["emitter_area"], slf)
+    ids = np.arange(int(g["H"]) * int(g["W"]), dtype=np.int32)
+    (Ld,) = oracle_mod.bake(sc, em, g["prim_position"], g["prim_normal"], 4, seed=9, stream=0, pix_id=ids)
+    a, b = oracle_mod.bake(sc, em, g["prim_position"], g["prim_normal"], 4, wo=-g["rays_d"], roughness=0.412, seed=9, stream=3, pix_id=ids)
+    np.testing.assert_array_equal(full, np.stack([Ld, a, b]))
