@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--lobes", type=str, default="0,1,2,3,4,5,6", help="0 = diffuse, 1..6 = specular roughness levels")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +110,7 @@ def main():
         m = 0
         rays = 0
         if 0 in lobes:
-            maps[m, g["sel"]] = bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"]); m += 1
+            maps[m, g["sel"]] = bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant); m += 1
             rays += P * spp
         for l in lobes:
             if l == 0:
@@ -117,7 +118,7 @@ def main():
             if record_events:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()      # torch's current stream == the stream the kernel is launched on (L.stream())
-            a, b = bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"])
+            a, b = bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"], variant=args.variant)
             if record_events:
                 e1.record(); ev_pairs.append((e0, e1, P * spp))
             maps[m, g["sel"]] = a; maps[m + 1, g["sel"]] = b; m += 2
@@ -167,10 +168,13 @@ def main():
         # algorithmic bytes/ray: instrumented launch of the same kernel on every 16th pixel, all six roughness levels
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         g = bs.primary_hits(scene, xs[pix_local], ds[pix_local], pixel_ids=pix_local)
-        sel = torch.arange(0, g["position"].shape[0], 16, device=dev)
+        # every 16th block of 8192 consecutive pixels (whole tiles, so that the tile-sorted kernel sees its real coherence)
+        nP = g["position"].shape[0]
+        sel = torch.arange(nP, device=dev)
+        sel = sel[(sel // 8192) % 16 == 3] if nP > 16 * 8192 else sel
         stats = torch.zeros(8, device=dev, dtype=torch.int64)
         for l in range(1, 7):
-            bs.bake_specular(scene, emitter, g["position"][sel], g["normal"][sel], g["wo"][sel], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"][sel], stats=stats)
+            bs.bake_specular(scene, emitter, g["position"][sel], g["normal"][sel], g["wo"][sel], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"][sel], stats=stats, variant=args.variant)
         torch.cuda.synchronize()
         st = stats.cpu().numpy().astype(np.float64)
         n_node, n_tri = st[1] / st[0], st[2] / st[0]
@@ -178,7 +182,7 @@ def main():
         # per-pixel traffic amortised over spp: pos+nrm+wo 36 B + pix_id 4 B in, 24 B out
         bytes_per_ray = n_node * info["node_bytes"] + n_tri * info["tri_bytes"] + (4 + 16 + 4 + info["tri_bytes"]) + (36 + 4 + 24) / spp
         achieved = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                               "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
                               "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3), "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),

@@ -109,20 +109,27 @@ IRIS_API int iris_eval_emitter(const iris_emitter *, const iris_slf *, const flo
                       const float *roughness, float trace_roughness, int64_t B, float *Le, float *emit_pdf,
                       uint8_t *valid_next, iris_stream_t);
 
+/* Kernel variants of the fused bake (kernel-choice experiments; AUTO picks TILE_SORTED when a workspace is given) */
+enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED = 2 };
+
 /* ---- a3..a7 fused: the bake loop body (bake_shading.py:108-123 diffuse, :168-188 specular) -------------- */
 /* pos,nrm[,wo]: (P,3) records of the valid pixels.  u2: (P*spp,2) explicit uniforms in the reference's order
  * (row = pixel*spp + sample), or NULL -> in-kernel Philox4x32-10 keyed by (seed, pix_id[p]*spp+s, stream);
  * pix_id (P) int32 nullable (defaults to p) makes the sample set independent of how pixels are sharded.
  * Ld/Ls0/Ls1: (P,3) = mean over spp of Le, Le*g0, Le*g1.  tri_next (P*spp) int64 nullable debug output.
  * stats: nullable device uint64[8]; when given, an INSTRUMENTED (slower) build of the kernel adds {rays, BVH node
- * visits, triangle tests, wave-level node steps, wave-level triangle steps} to it (used to price the roofline). */
+ * visits, triangle tests, wave-level node steps, wave-level triangle steps} to it (used to price the roofline).
+ * workspace: device scratch of iris_bake_workspace_bytes() bytes for the tile-sorted kernel (per-ray results parked
+ * between the trace and the reduction phases); NULL selects the pixel-per-wave kernel.  Both give identical bits. */
+IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular);
 IRIS_API int iris_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                       int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,
-                      float *Ld, int64_t *tri_next, uint64_t *stats, iris_stream_t);
+                      float *Ld, int64_t *tri_next, uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes,
+                      iris_stream_t);
 IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                        const float *wo, float roughness, int64_t P, int spp, const float *u2, uint64_t seed,
                        uint32_t stream_id, const int32_t *pix_id, float *Ls0, float *Ls1, int64_t *tri_next,
-                       uint64_t *stats, iris_stream_t);
+                       uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes, iris_stream_t);
 
 /* ---- a10: lerp_specular (utils/ops.py:99-118): specular (B,R,3), roughness (B) -> (B,3) ------------------ */
 IRIS_API int iris_lerp_specular(const float *specular, const float *roughness, int64_t B, int R, float *out, iris_stream_t);

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiris_hip.so")
 
 BVH_DEFAULT, BVH4_F32, BVH8_Q8 = 0, 1, 2
+BAKE_AUTO, BAKE_PIXEL_PER_WAVE, BAKE_TILE_SORTED = 0, 1, 2
 
 
 class IrisError(RuntimeError):
@@ -39,15 +40,16 @@ PROTOTYPES = {
     "iris_sample_specular": [_P, _P, _P, _F, _I64, _P, _P, _P, _P, _P],
     "iris_slf_lookup": [_P, _P, _I64, _P, _P, _P],
     "iris_eval_emitter": [_P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P],
-    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P],
-    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _P],
+    "iris_bake_workspace_bytes": [_I64, _I32, _I32],
+    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _I32, _P, _U64, _P],
+    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
     "iris_last_error": [],
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64}
 
 _lib = None
 

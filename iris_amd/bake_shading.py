@@ -41,19 +41,34 @@ def _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri):
     return position, normal, P, dev, u2, pix_id, tri
 
 
-def bake_diffuse(scene, emitter, position, normal, spp=SPP_DIFFUSE, u2=None, seed=0, stream_id=0, pix_id=None, want_tri=False, stats=None):
+def _workspace(P, spp, specular, variant, dev):
+    """Scratch of the tile-sorted kernel (per-ray results between its trace and reduce phases); a torch allocation so
+    that it is stream-ordered like every other tensor."""
+    if variant == L.BAKE_PIXEL_PER_WAVE:
+        return None, 0
+    n = int(L.lib().iris_bake_workspace_bytes(P, int(spp), int(specular)))
+    if n == 0:
+        return None, 0
+    return torch.empty(n, device=dev, dtype=torch.uint8), n
+
+
+def bake_diffuse(scene, emitter, position, normal, spp=SPP_DIFFUSE, u2=None, seed=0, stream_id=0, pix_id=None, want_tri=False, stats=None,
+                 variant=L.BAKE_AUTO):
     """Ld_ of bake_shading.py:108-123 for all P valid pixels: mean over spp of Le along cosine-sampled rays.
     u2: optional (P*spp,2) uniforms in the reference's order (parity mode); otherwise in-kernel Philox.
     stats: optional zeroed int64[8] device tensor -> instrumented launch (rays, node visits, tri tests, ...)."""
     position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
     Ld = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    ws, ws_bytes = _workspace(P, spp, False, variant, dev)
     with torch.cuda.device(dev):
         L.check(L.lib().iris_bake_diffuse(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal),
-                                          P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ld), L.ptr(tri), L.ptr(stats), L.stream()))
+                                          P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ld), L.ptr(tri), L.ptr(stats),
+                                          int(variant), L.ptr(ws), ws_bytes, L.stream()))
     return (Ld, tri) if want_tri else Ld
 
 
-def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None, seed=0, stream_id=1, pix_id=None, want_tri=False, stats=None):
+def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None, seed=0, stream_id=1, pix_id=None, want_tri=False,
+                  stats=None, variant=L.BAKE_AUTO):
     """Ls0_, Ls1_ of bake_shading.py:168-188 for one roughness level."""
     position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
     wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
@@ -61,10 +76,11 @@ def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None,
         roughness = float(roughness.detach().float().cpu().item())
     Ls0 = torch.empty(P, 3, device=dev, dtype=torch.float32)
     Ls1 = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    ws, ws_bytes = _workspace(P, spp, True, variant, dev)
     with torch.cuda.device(dev):
         L.check(L.lib().iris_bake_specular(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo),
                                            roughness, P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ls0), L.ptr(Ls1),
-                                           L.ptr(tri), L.ptr(stats), L.stream()))
+                                           L.ptr(tri), L.ptr(stats), int(variant), L.ptr(ws), ws_bytes, L.stream()))
     return (Ls0, Ls1, tri) if want_tri else (Ls0, Ls1)
 
 

@@ -1,0 +1,283 @@
+// Fused bake kernels (bake_shading.py:108-123 diffuse, :168-188 specular): uniforms -> BRDF sample -> secondary-ray
+// traversal -> SLF / emitter lookup -> weights -> mean over spp, one launch per lobe.
+//
+//   bake_kernel       v1: one pixel per wave, lanes = samples (maximally incoherent rays inside a wave).
+//   bake_tile_kernel  v2: a workgroup owns a TILE of consecutive pixels (<= 8192 rays), bins the tile's rays by direction
+//                     (octahedral 16x16 map, Morton order) with an LDS counting sort, traces them in sorted order (a wave's 64
+//                     rays share a narrow direction cone and nearby origins -> their node fetches coalesce and their
+//                     traversal lengths match), parks per-ray results in a workgroup-private HBM scratch and finally
+//                     reduces each pixel's samples in the SAME fixed order as v1 -> v1 and v2 are bit-identical.
+#pragma once
+#include "iris_trace.h"
+
+namespace iris {
+
+struct BakeArgs {
+    SceneDev sc; EmitDev em; SlfDev slf;
+    const float* pos; const float* nrm; const float* wo;
+    const float* u2; const int32_t* pix_id;
+    int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
+    float* out0; float* out1; int64_t* tri_next;
+    unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
+    // v2 only
+    float* scratch;             // gridDim.x * kTileRays * (SPEC ? 6 : 3) floats
+    unsigned int* tile_counter; // zeroed before the launch
+    int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
+};
+
+constexpr int kTileRays = 8192;
+
+// lanes-per-pixel / pixels-per-wave geometry of the per-pixel reduction (shared by v1 and v2 so that the sums match)
+__device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int& rounds) {
+    if (spp >= 64) { lpp = 64; ppw = 1; rounds = (spp + 63) >> 6; }
+    else if ((spp & (spp - 1)) == 0) { lpp = spp; ppw = 64 / spp; rounds = 1; }
+    else { lpp = 64; ppw = 1; rounds = 1; }
+}
+
+struct RayOut { float r0, g0, b0, r1, g1, b1; };
+
+// One (pixel, sample): sample the lobe, trace, shade.  Everything between the uniforms and Le*g stays in registers.
+template <bool SPEC, bool COUNT, int LDS_DEPTH = kStackLds>
+__device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int s, f3 x, f3 n, f3 w, f3 t, f3 b, uint64_t base,
+                                               uint32_t* lds_stack, TraceStats* ts, uint32_t& n_rays) {
+    float u0, u1;
+    if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
+    else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+    f3 wi; float g0 = 1.f, g1 = 0.f;
+    if (SPEC) {
+        wi = specular_sampler(u0, u1, a.rough, w, n, t, b);
+        SpecW sw = specular_weights(wi, w, n, a.rough, false);
+        g0 = sw.g0; g1 = sw.g1;
+    } else {
+        wi = diffuse_sampler(u0, u1, n, t, b);
+    }
+    // position + RayEpsilon*wi  (bake_shading.py:117, :180)
+    f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
+    Hit h = trace_bvh4<COUNT, LDS_DEPTH>(a.sc, o, wi, lds_stack, ts);
+    if (COUNT) n_rays++;
+    f3 pn = mk3(0.f, 0.f, 0.f);
+    int64_t tri = -1;
+    if (h.slot >= 0) {
+        f3 p0, p1, p2;
+        hit_vertices(a.sc, h, p0, p1, p2);
+        pn = hit_position(h, p0, p1, p2);
+        tri = h.id;
+    }
+    if (a.tri_next) a.tri_next[p * a.spp + s] = tri;
+    // eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0)  (bake_shading.py:121-122, :184-185)
+    float epdf; bool vn;
+    f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
+    RayOut r;
+    if (SPEC) { r.r0 = Le.x * g0; r.g0 = Le.y * g0; r.b0 = Le.z * g0; r.r1 = Le.x * g1; r.g1 = Le.y * g1; r.b1 = Le.z * g1; }
+    else { r.r0 = Le.x; r.g0 = Le.y; r.b0 = Le.z; r.r1 = r.g1 = r.b1 = 0.f; }
+    return r;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats& ts, uint32_t n_rays) {
+    if (COUNT) {
+        uint32_t v[5] = {n_rays, ts.nodes, ts.tris, ts.node_iters, ts.leaf_iters};
+        for (int k = 0; k < 5; ++k) {
+            uint32_t x = v[k];
+            for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+            if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + k, (unsigned long long)x);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------- v1
+template <bool SPEC, bool COUNT>
+__global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const int lane = threadIdx.x & 63;
+    const int spp = a.spp;
+    int lpp, ppw, rounds;
+    reduce_geometry(spp, lpp, ppw, rounds);
+    const int sub = lane / lpp, sl = lane - sub * lpp;
+    const int64_t n_groups = (a.P + ppw - 1) / ppw;
+    const int64_t wave0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const float inv_spp = 1.0f / (float)spp;
+    TraceStats ts;
+    uint32_t n_rays = 0;
+
+    for (int64_t g = wave0; g < n_groups; g += n_waves) {
+        const int64_t p = g * ppw + sub;
+        const bool pvalid = p < a.P;
+        f3 x = mk3(0.f, 0.f, 0.f), n = mk3(0.f, 0.f, 1.f), w = mk3(0.f, 0.f, 1.f), t, b;
+        uint64_t base = 0;
+        if (pvalid) {
+            x = ld3(a.pos + p * 3); n = ld3(a.nrm + p * 3);
+            if (SPEC) w = ld3(a.wo + p * 3);
+            base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+        }
+        normal_space(n, t, b);
+        float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int r = 0; r < rounds; ++r) {
+            const int s = r * 64 + sl;
+            if (pvalid && s < spp) {
+                RayOut o = shade_sample<SPEC, COUNT>(a, p, s, x, n, w, t, b, base, s_stack + threadIdx.x, &ts, n_rays);
+                a0x += o.r0; a0y += o.g0; a0z += o.b0;
+                if (SPEC) { a1x += o.r1; a1y += o.g1; a1z += o.b1; }
+            }
+        }
+        // .reshape(b,spp,3).mean(1): fixed butterfly over the lpp lanes of the pixel
+        for (int m = 1; m < lpp; m <<= 1) {
+            a0x += __shfl_xor(a0x, m); a0y += __shfl_xor(a0y, m); a0z += __shfl_xor(a0z, m);
+            if (SPEC) { a1x += __shfl_xor(a1x, m); a1y += __shfl_xor(a1y, m); a1z += __shfl_xor(a1z, m); }
+        }
+        if (pvalid && sl == 0) {
+            st3(a.out0 + p * 3, mk3(a0x * inv_spp, a0y * inv_spp, a0z * inv_spp));
+            if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
+        }
+    }
+    flush_stats<COUNT>(a, ts, n_rays);
+}
+
+// ------------------------------------------------------------------------------------------------------- v2
+// Direction bin: octahedral map of the unit vector to [0,1)^2, 16x16 cells, Morton-interleaved (adjacent codes = adjacent cones)
+__device__ __forceinline__ uint32_t dir_bin(f3 d) {
+    float inv = 1.0f / (fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);
+    float px = d.x * inv, py = d.y * inv;
+    if (d.z < 0.f) {
+        float qx = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
+        float qy = (1.f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
+        px = qx; py = qy;
+    }
+    int ix = min(15, max(0, (int)((px * 0.5f + 0.5f) * 16.f)));
+    int iy = min(15, max(0, (int)((py * 0.5f + 0.5f) * 16.f)));
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m |= (((uint32_t)ix >> k) & 1u) << (2 * k) | (((uint32_t)iy >> k) & 1u) << (2 * k + 1);
+    return m;
+}
+
+template <bool SPEC>
+__device__ __forceinline__ f3 sample_direction(const BakeArgs& a, int64_t p, int s, f3 n, f3 w, f3 t, f3 b, uint64_t base) {
+    float u0, u1;
+    if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
+    else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+    return SPEC ? specular_sampler(u0, u1, a.rough, w, n, t, b) : diffuse_sampler(u0, u1, n, t, b);
+}
+
+template <bool SPEC, bool COUNT>
+__global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
+    // LDS: sorted ray list (16 KiB) + traversal stacks (24 KiB).  The stack region doubles as the sort's key / histogram
+    // storage: the two uses are separated by workgroup barriers.
+    constexpr int kTileStack = kStackLds - 1;  // 16384 + 23552 + 8 B = 39944 B <= 160 KiB / 4 -> four workgroups per CU
+    __shared__ uint16_t s_sorted[kTileRays];
+    __shared__ uint32_t s_stack[kTileStack * kBlock];
+    __shared__ int s_tile, s_chunk;
+    static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
+    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
+    uint32_t* s_hist = s_stack + kTileRays / 4;
+    uint32_t* s_cur = s_hist + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int spp = a.spp;
+    constexpr int NC = SPEC ? 6 : 3;
+    float* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
+    const int64_t n_tiles = (a.P + a.tile_px - 1) / a.tile_px;
+    int lpp, ppw, rounds;
+    reduce_geometry(spp, lpp, ppw, rounds);
+    const int sub = lane / lpp, sl = lane - sub * lpp;
+    const float inv_spp = 1.0f / (float)spp;
+    TraceStats ts;
+    uint32_t n_rays = 0;
+
+    for (;;) {
+        __syncthreads();  // previous tile fully done with LDS
+        if (tid == 0) { s_tile = (int)atomicAdd(a.tile_counter, 1u); s_chunk = 0; }
+        s_hist[tid] = 0;  // kBlock == 256 bins
+        __syncthreads();
+        const int64_t tile = s_tile;
+        if (tile >= n_tiles) break;
+        const int64_t p0 = tile * a.tile_px;
+        const int np = (int)min((int64_t)a.tile_px, a.P - p0);
+        const int nr = np * spp;
+
+        // ---- phase A: direction bin of every ray of the tile, histogram
+        for (int r = tid; r < nr; r += kBlock) {
+            const int pl = r / spp, s = r - pl * spp;
+            const int64_t p = p0 + pl;
+            f3 n = ld3(a.nrm + p * 3), w = mk3(0.f, 0.f, 1.f), t, b;
+            if (SPEC) w = ld3(a.wo + p * 3);
+            normal_space(n, t, b);
+            const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+            const uint32_t key = dir_bin(sample_direction<SPEC>(a, p, s, n, w, t, b, base));
+            s_keys[r] = (uint8_t)key;
+            atomicAdd(&s_hist[key], 1u);
+        }
+        __syncthreads();
+        // ---- exclusive prefix over the 256 bins (wave 0: 4 bins per lane)
+        if (wave == 0) {
+            uint32_t c0 = s_hist[lane * 4], c1 = s_hist[lane * 4 + 1], c2 = s_hist[lane * 4 + 2], c3 = s_hist[lane * 4 + 3];
+            uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
+            for (int m = 1; m < 64; m <<= 1) { uint32_t v = __shfl_up(inc, m); if (lane >= m) inc += v; }
+            uint32_t ex = inc - tot;
+            s_cur[lane * 4] = ex; s_cur[lane * 4 + 1] = ex + c0; s_cur[lane * 4 + 2] = ex + c0 + c1; s_cur[lane * 4 + 3] = ex + c0 + c1 + c2;
+        }
+        __syncthreads();
+        // ---- phase B: scatter ray ids into bin order (order inside a bin is irrelevant: results go to per-ray slots)
+        for (int r = tid; r < nr; r += kBlock) {
+            const uint32_t pos = atomicAdd(&s_cur[s_keys[r]], 1u);
+            s_sorted[pos] = (uint16_t)r;
+        }
+        __syncthreads();  // keys / histogram dead from here on: the region becomes the traversal stacks
+
+        // ---- phase C: trace in sorted order, 64 consecutive sorted rays per wave-iteration
+        for (;;) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(&s_chunk, 1);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c * 64 >= nr) break;
+            const int i = c * 64 + lane;
+            if (i < nr) {
+                const int r = s_sorted[i];
+                const int pl = r / spp, s = r - pl * spp;
+                const int64_t p = p0 + pl;
+                f3 x = ld3(a.pos + p * 3), n = ld3(a.nrm + p * 3), w = mk3(0.f, 0.f, 1.f), t, b;
+                if (SPEC) w = ld3(a.wo + p * 3);
+                normal_space(n, t, b);
+                const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+                RayOut o = shade_sample<SPEC, COUNT, kTileStack>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
+                float* q = res + (size_t)r * NC;
+                q[0] = o.r0; q[1] = o.g0; q[2] = o.b0;
+                if (SPEC) { q[3] = o.r1; q[4] = o.g1; q[5] = o.b1; }
+            }
+        }
+        // results were written by other waves of this workgroup, possibly to lines this CU's L1 still holds from the
+        // previous tile: release, barrier, acquire (agent scope) before reading them back
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+
+        // ---- phase D: per-pixel mean in the fixed order of v1 (lane-strided partial sums, xor butterfly)
+        const int n_groups = (np + ppw - 1) / ppw;
+        for (int g = wave; g < n_groups; g += kBlock / 64) {
+            const int pl = g * ppw + sub;
+            const bool pvalid = pl < np;
+            float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+            for (int rr = 0; rr < rounds; ++rr) {
+                const int s = rr * 64 + sl;
+                if (pvalid && s < spp) {
+                    const float* q = res + (size_t)(pl * spp + s) * NC;
+                    a0x += q[0]; a0y += q[1]; a0z += q[2];
+                    if (SPEC) { a1x += q[3]; a1y += q[4]; a1z += q[5]; }
+                }
+            }
+            for (int m = 1; m < lpp; m <<= 1) {
+                a0x += __shfl_xor(a0x, m); a0y += __shfl_xor(a0y, m); a0z += __shfl_xor(a0z, m);
+                if (SPEC) { a1x += __shfl_xor(a1x, m); a1y += __shfl_xor(a1y, m); a1z += __shfl_xor(a1z, m); }
+            }
+            if (pvalid && sl == 0) {
+                const int64_t p = p0 + pl;
+                st3(a.out0 + p * 3, mk3(a0x * inv_spp, a0y * inv_spp, a0z * inv_spp));
+                if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
+            }
+        }
+    }
+    flush_stats<COUNT>(a, ts, n_rays);
+}
+
+}  // namespace iris

@@ -12,6 +12,7 @@
 #include "bvh_build.h"
 #include "iris_device.h"
 #include "iris_trace.h"
+#include "iris_bake.h"
 
 using namespace iris;
 
@@ -451,140 +452,79 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 }
 
 // ======================================================================================================
-// a3..a7 fused bake kernel  (bake_shading.py:108-123 / :168-188)
-//
-// Work decomposition: a wave owns `ppw` consecutive pixels per iteration and its 64 lanes are that group's
-// samples (lane -> (pixel, sample)); the spp samples of a pixel are reduced with a fixed xor-butterfly, so the
-// result is deterministic.  Waves stride over the pixel groups (persistent grid = CUs x resident workgroups).
-// Nothing per-sample ever goes to HBM: uniforms (Philox) -> direction -> BVH traversal -> SLF/emitter gather ->
-// weights -> reduction all stay in registers/LDS; per pixel the kernel reads 24-36 B and writes 12-24 B.
+// a3..a7 fused bake kernels (iris_bake.h)
 // ======================================================================================================
-struct BakeArgs {
-    SceneDev sc; EmitDev em; SlfDev slf;
-    const float* pos; const float* nrm; const float* wo;
-    const float* u2; const int32_t* pix_id;
-    int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
-    float* out0; float* out1; int64_t* tri_next;
-    unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
-};
+static int bake_grid_blocks() { return num_cus() * 4; }  // 4 resident 256-thread workgroups per CU (VGPR- and LDS-bound)
 
-template <bool SPEC, bool COUNT>
-__global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
-    __shared__ uint32_t s_stack[kStackLds * kBlock];
-    const int lane = threadIdx.x & 63;
-    const int spp = a.spp;
-    int lpp, ppw, rounds;  // lanes per pixel, pixels per wave-iteration, rounds of 64 samples
-    if (spp >= 64) { lpp = 64; ppw = 1; rounds = (spp + 63) >> 6; }
-    else if ((spp & (spp - 1)) == 0) { lpp = spp; ppw = 64 / spp; rounds = 1; }
-    else { lpp = 64; ppw = 1; rounds = 1; }
-    const int sub = lane / lpp, sl = lane - sub * lpp;
-    const int64_t n_groups = (a.P + ppw - 1) / ppw;
-    const int64_t wave0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
-    const float inv_spp = 1.0f / (float)spp;
-    TraceStats ts;
-    uint32_t n_rays = 0;
-
-    for (int64_t g = wave0; g < n_groups; g += n_waves) {
-        const int64_t p = g * ppw + sub;
-        const bool pvalid = p < a.P;
-        f3 x = mk3(0.f, 0.f, 0.f), n = mk3(0.f, 0.f, 1.f), w = mk3(0.f, 0.f, 1.f), t, b;
-        uint64_t base = 0;
-        if (pvalid) {
-            x = ld3(a.pos + p * 3); n = ld3(a.nrm + p * 3);
-            if (SPEC) w = ld3(a.wo + p * 3);
-            base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
-        }
-        normal_space(n, t, b);
-        float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
-        for (int r = 0; r < rounds; ++r) {
-            const int s = r * 64 + sl;
-            if (pvalid && s < spp) {
-                float u0, u1;
-                if (a.u2) { const float* up = a.u2 + ((int64_t)p * spp + s) * 2; u0 = up[0]; u1 = up[1]; }
-                else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
-                f3 wi; float g0 = 1.f, g1 = 0.f;
-                if (SPEC) {
-                    wi = specular_sampler(u0, u1, a.rough, w, n, t, b);
-                    SpecW sw = specular_weights(wi, w, n, a.rough, false);
-                    g0 = sw.g0; g1 = sw.g1;
-                } else {
-                    wi = diffuse_sampler(u0, u1, n, t, b);
-                }
-                // position + RayEpsilon*wi  (bake_shading.py:117, :180)
-                f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-                Hit h = trace_bvh4<COUNT>(a.sc, o, wi, s_stack + threadIdx.x, &ts);
-                if (COUNT) n_rays++;
-                f3 pn = mk3(0.f, 0.f, 0.f);
-                int64_t tri = -1;
-                if (h.slot >= 0) {
-                    f3 p0, p1, p2;
-                    hit_vertices(a.sc, h, p0, p1, p2);
-                    pn = hit_position(h, p0, p1, p2);
-                    tri = h.id;
-                }
-                if (a.tri_next) a.tri_next[(int64_t)p * spp + s] = tri;
-                // eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0)  (bake_shading.py:121-122, :184-185)
-                float epdf; bool vn;
-                f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
-                if (SPEC) {
-                    a0x += Le.x * g0; a0y += Le.y * g0; a0z += Le.z * g0;
-                    a1x += Le.x * g1; a1y += Le.y * g1; a1z += Le.z * g1;
-                } else { a0x += Le.x; a0y += Le.y; a0z += Le.z; }
-            }
-        }
-        // .reshape(b,spp,3).mean(1): fixed butterfly over the lpp lanes of the pixel
-        for (int m = 1; m < lpp; m <<= 1) {
-            a0x += __shfl_xor(a0x, m); a0y += __shfl_xor(a0y, m); a0z += __shfl_xor(a0z, m);
-            if (SPEC) { a1x += __shfl_xor(a1x, m); a1y += __shfl_xor(a1y, m); a1z += __shfl_xor(a1z, m); }
-        }
-        if (pvalid && sl == 0) {
-            st3(a.out0 + p * 3, mk3(a0x * inv_spp, a0y * inv_spp, a0z * inv_spp));
-            if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
-        }
-    }
-    if (COUNT) {
-        uint32_t v[5] = {n_rays, ts.nodes, ts.tris, ts.node_iters, ts.leaf_iters};
-        for (int k = 0; k < 5; ++k) {
-            uint32_t x = v[k];
-            for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
-            if (lane == 0) atomicAdd(a.stats + k, (unsigned long long)x);
-        }
-    }
+extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
+    (void)P;
+    if (spp < 1 || spp > kTileRays) return 0;  // v1 kernel only
+    return 256 + (uint64_t)bake_grid_blocks() * kTileRays * (specular ? 6 : 3) * sizeof(float);
 }
 
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                        const float* wo, float rough, int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id,
-                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, uint64_t* stats, iris_stream_t stream) {
+                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, uint64_t* stats, int variant,
+                       void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
     if (!sc || !em || !slf || P < 0 || spp < 1 || (P > 0 && (!pos || !nrm || !out0 || (spec && (!wo || !out1)))))
         return fail(IRIS_ERR_ARG, "iris_bake: bad arguments");
+    if (variant < IRIS_BAKE_AUTO || variant > IRIS_BAKE_TILE_SORTED) return fail(IRIS_ERR_ARG, "iris_bake: unknown kernel variant");
     if (P == 0) return IRIS_OK;
     BakeArgs a{};
     a.sc = sc->dev; a.em = em->dev; a.slf = slf->dev;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.u2 = u2; a.pix_id = pix_id;
     a.P = P; a.spp = spp; a.seed = seed; a.stream_id = stream_id; a.rough = rough;
     a.out0 = out0; a.out1 = out1; a.tri_next = tri_next; a.stats = (unsigned long long*)stats;
-    const int ppw = (spp < 64 && (spp & (spp - 1)) == 0) ? 64 / spp : 1;
-    const int64_t n_groups = (P + ppw - 1) / ppw;
-    const int grid = grid_for(n_groups * 64, kBlock, num_cus() * 6);
-    if (stats) {
-        if (spec) hipLaunchKernelGGL((bake_kernel<true, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((bake_kernel<false, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    const uint64_t need = iris_bake_workspace_bytes(P, spp, spec ? 1 : 0);
+    bool tiled = variant != IRIS_BAKE_PIXEL_PER_WAVE && need > 0 && workspace && workspace_bytes >= need;
+    if (variant == IRIS_BAKE_TILE_SORTED && !tiled)
+        return fail(IRIS_ERR_ARG, "iris_bake: the tile-sorted kernel needs spp <= 8192 and a workspace of iris_bake_workspace_bytes()");
+    hipStream_t st = (hipStream_t)stream;
+    if (tiled) {
+        const int blocks = bake_grid_blocks();
+        int tile_px = kTileRays / spp;                       // as many pixels as fit the LDS ray list ...
+        const int64_t even = (P + blocks - 1) / blocks;      // ... but never fewer tiles than workgroups
+        if (even < tile_px) tile_px = (int)even;
+        if (tile_px < 1) tile_px = 1;
+        a.tile_px = tile_px;
+        a.tile_counter = (unsigned int*)workspace;
+        a.scratch = (float*)((char*)workspace + 256);
+        HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+        const int64_t n_tiles = (P + tile_px - 1) / tile_px;
+        const int grid = (int)std::min<int64_t>(blocks, n_tiles);
+        if (stats) {
+            if (spec) hipLaunchKernelGGL((bake_tile_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+            else hipLaunchKernelGGL((bake_tile_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        } else {
+            if (spec) hipLaunchKernelGGL((bake_tile_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+            else hipLaunchKernelGGL((bake_tile_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        }
     } else {
-        if (spec) hipLaunchKernelGGL((bake_kernel<true, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((bake_kernel<false, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+        const int ppw = (spp < 64 && (spp & (spp - 1)) == 0) ? 64 / spp : 1;
+        const int64_t n_groups = (P + ppw - 1) / ppw;
+        const int grid = grid_for(n_groups * 64, kBlock, num_cus() * 6);
+        if (stats) {
+            if (spec) hipLaunchKernelGGL((bake_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+            else hipLaunchKernelGGL((bake_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        } else {
+            if (spec) hipLaunchKernelGGL((bake_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+            else hipLaunchKernelGGL((bake_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        }
     }
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
 extern "C" IRIS_API int iris_bake_diffuse(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                                  int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id, const int32_t* pix_id,
-                                 float* Ld, int64_t* tri_next, uint64_t* stats, iris_stream_t stream) {
-    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, stats, stream);
+                                 float* Ld, int64_t* tri_next, uint64_t* stats, int variant, void* workspace, uint64_t workspace_bytes,
+                                 iris_stream_t stream) {
+    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, stats, variant,
+                       workspace, workspace_bytes, stream);
 }
 extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                                   const float* wo, float roughness, int64_t P, int spp, const float* u2, uint64_t seed,
                                   uint32_t stream_id, const int32_t* pix_id, float* Ls0, float* Ls1, int64_t* tri_next,
-                                  uint64_t* stats, iris_stream_t stream) {
-    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stats, stream);
+                                  uint64_t* stats, int variant, void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
+    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stats, variant,
+                       workspace, workspace_bytes, stream);
 }

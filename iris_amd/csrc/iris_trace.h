@@ -30,18 +30,19 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
     return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : 1.0f / d;
 }
 
+template <int LDS_DEPTH>
 struct Stack {
     uint32_t* lds;  // &s_stack[threadIdx.x]
-    uint32_t spill[kStackSpill];
+    uint32_t spill[kStackLds + kStackSpill - LDS_DEPTH];
     int sp;
     __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < kStackLds) lds[sp * kBlock] = v;
-        else spill[min(sp - kStackLds, kStackSpill - 1)] = v;
+        if (sp < LDS_DEPTH) lds[sp * kBlock] = v;
+        else spill[min(sp - LDS_DEPTH, kStackLds + kStackSpill - LDS_DEPTH - 1)] = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return sp < kStackLds ? lds[sp * kBlock] : spill[min(sp - kStackLds, kStackSpill - 1)];
+        return sp < LDS_DEPTH ? lds[sp * kBlock] : spill[min(sp - LDS_DEPTH, kStackLds + kStackSpill - LDS_DEPTH - 1)];
     }
 };
 
@@ -84,13 +85,13 @@ __device__ __forceinline__ bool first_active_lane() {
     return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
 }
 
-template <bool COUNT = false>
+template <bool COUNT = false, int LDS_DEPTH = kStackLds>
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr) {
     Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
     const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
     const float nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
     const bool px = ix >= 0.f, py = iy >= 0.f, pz = iz >= 0.f;
-    Stack st; st.lds = lds_stack; st.sp = 0;
+    Stack<LDS_DEPTH> st; st.lds = lds_stack; st.sp = 0;
     uint32_t cur = 0;  // root
     while (cur != kEmptyRef) {
         while (!(cur & kLeafBit)) {

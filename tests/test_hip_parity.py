@@ -354,6 +354,27 @@ def test_bake_properties_full_size(dev, room_setup):
     assert torch.equal(Ld3, Ld1 * 2.0)
 
 
+@pytest.mark.parametrize("spp", [1, 16, 20, 64, 100, 128, 256])
+def test_bake_kernel_variants_bit_identical(dev, room_setup, spp):
+    """The pixel-per-wave kernel and the tile-sorted kernel reduce in the same fixed order: identical bits."""
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    P = len(s["pos"]) if spp <= 64 else 1111
+    pos, nrm, wo = T(s["pos"][:P], dev), T(s["nrm"][:P], dev), T(s["wo"][:P], dev)
+    a1, t1 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, seed=2, want_tri=True, variant=L.BAKE_PIXEL_PER_WAVE)
+    a2, t2 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, seed=2, want_tri=True, variant=L.BAKE_TILE_SORTED)
+    assert torch.equal(t1, t2) and torch.equal(a1, a2)
+    b1 = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 0.216, spp, seed=2, stream_id=2, variant=L.BAKE_PIXEL_PER_WAVE)
+    b2 = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 0.216, spp, seed=2, stream_id=2, variant=L.BAKE_TILE_SORTED)
+    assert torch.equal(b1[0], b2[0]) and torch.equal(b1[1], b2[1])
+    # explicit uniforms (parity mode) through both kernels
+    u2 = torch.rand(P * spp, 2, device=dev)
+    c1 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, u2=u2, variant=L.BAKE_PIXEL_PER_WAVE)
+    c2 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, u2=u2, variant=L.BAKE_TILE_SORTED)
+    assert torch.equal(c1, c2)
+
+
 def test_bake_view_layout(dev, room_setup):
     """bake_view returns the 13 maps of one view in image order with zeros at invalid pixels."""
     from tools import synth
