@@ -47,10 +47,25 @@ __device__ __forceinline__ void normal_space(f3 n, f3& t, f3& b) {
 __device__ __forceinline__ f3 to_world(f3 l, f3 t, f3 b, f3 n) {
     return mk3((l.x * t.x + l.y * b.x) + l.z * n.x, (l.x * t.y + l.y * b.y) + l.z * n.y, (l.x * t.z + l.y * b.z) + l.z * n.z);
 }
+// sin/cos of phi in [0, 2*pi] with a fully specified IEEE operation sequence (Cody-Waite reduction by pi/4 octants +
+// the classic single-precision minimax polynomials; no fma, no libm), so that the CPU oracle's "device arithmetic"
+// mode reproduces it bit for bit.  |error| <= ~1.2e-7 absolute, i.e. the same class as libm / torch's SLEEF.
+__device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
+    int j = (int)(x * 1.27323954473516f);  // 4/pi
+    j = (j + 1) & ~1;
+    const float y = (float)j;
+    const float z = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float zz = z * z;
+    const float ps = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
+    const float pc = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
+    const int q = (j >> 1) & 3;
+    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
 // utils/ops.py:32-44 angle2xyz given sin(theta), cos(theta) and phi
 __device__ __forceinline__ f3 angle2xyz_sc(float st, float ct, float phi) {
     float sp, cp;
-    sincosf(phi, &sp, &cp);
+    spec_sincos(phi, sp, cp);
     return t_normalize(mk3(st * cp, st * sp, ct));
 }
 

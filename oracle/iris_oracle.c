@@ -159,6 +159,38 @@ static inline v3 to_world(v3 l, v3 t, v3 b, v3 n) {
     return v3_make((l.x * t.x + l.y * b.x) + l.z * n.x, (l.x * t.y + l.y * b.y) + l.z * n.y,
                    (l.x * t.z + l.y * b.z) + l.z * n.z);
 }
+/* ---- "device arithmetic" mode -------------------------------------------------------------------------------
+ * mode 0 (default): the literal restatement above/below (libm asinf/acosf/sinf/cosf/powf) -- this is what is pinned
+ *                   against the reference's golden vectors.
+ * mode 1          : the same algorithm with the transcendental round trips replaced by the exactly specified IEEE
+ *                   operation sequences the HIP kernels use (iris_amd/csrc/iris_device.h): sin(asin(s)) = s,
+ *                   cos(asin(s)) = sqrt((1-s)(1+s)), cos(acos(c)) = c, sin(acos(c)) = sqrt((1-c)(1+c)), a Cody-Waite +
+ *                   polynomial sincos, x^5 by multiplication, and the kernels' fixed reduction order for the mean over
+ *                   spp.  Mode 1 exists so that GPU results can be compared BIT FOR BIT at any size (the SLF / emitter
+ *                   lookups are discontinuous, so 1-ulp differences in a direction flip rare samples by O(1)); it is
+ *                   itself checked against mode 0 / the goldens within float tolerance by the CPU tests. */
+static int g_mode = 0;
+ORC_API void orc_set_mode(int m) { g_mode = m; }
+ORC_API int orc_get_mode(void) { return g_mode; }
+
+static inline void spec_sincos(float x, float *s, float *c) {
+    int j = (int)(x * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    const float y = (float)j;
+    const float z = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float zz = z * z;
+    const float ps = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
+    const float pc = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
+    const int q = (j >> 1) & 3;
+    *s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    *c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+static inline v3 angle2xyz_sc(float st, float ct, float phi) {
+    float sp, cp;
+    spec_sincos(phi, &sp, &cp);
+    return t_normalize(v3_make(st * cp, st * sp, ct));
+}
+
 /* utils/ops.py:85-96 double_sided(V,N) (in place on N) */
 ORC_API void orc_double_sided(const float *V, float *N, int64_t B) {
     for (int64_t i = 0; i < B; ++i) {
@@ -169,9 +201,16 @@ ORC_API void orc_double_sided(const float *V, float *N, int64_t B) {
 
 /* model/brdf.py:20-34 diffuse_sampler */
 static inline v3 diffuse_sampler(float u0, float u1, v3 n) {
-    float theta = asinf(sqrtf(u0));
     float phi = TWO_PI_F * u1;
-    v3 l = angle2xyz(theta, phi), t, b;
+    v3 l, t, b;
+    if (g_mode == 1) {
+        float s = sqrtf(u0);
+        float c = sqrtf(fmaxf((1.f - s) * (1.f + s), 0.f));
+        l = angle2xyz_sc(s, c, phi);
+    } else {
+        float theta = asinf(sqrtf(u0));
+        l = angle2xyz(theta, phi);
+    }
     normal_space(n, &t, &b);
     return to_world(l, t, b, n);
 }
@@ -191,9 +230,16 @@ ORC_API void orc_sample_diffuse(const float *u2, const float *normal, int64_t B,
 static inline v3 specular_sampler(float u0, float u1, float rough, v3 wo, v3 n) {
     float alpha = rough * rough;
     float c2 = (1.f - u0) / (u0 * (alpha * alpha - 1.f) + 1.f);
-    float theta = acosf(sqrtf(c2));
     float phi = TWO_PI_F * u1;
-    v3 l = angle2xyz(theta, phi), t, b;
+    v3 l, t, b;
+    if (g_mode == 1) {
+        float cs = sqrtf(c2);
+        float sn = sqrtf(fmaxf((1.f - cs) * (1.f + cs), 0.f));
+        l = angle2xyz_sc(sn, cs, phi);
+    } else {
+        float theta = acosf(sqrtf(c2));
+        l = angle2xyz(theta, phi);
+    }
     normal_space(n, &t, &b);
     v3 wh = to_world(l, t, b, n);
     float s = 2.f * t_dot(wo, wh);
@@ -213,7 +259,10 @@ static inline float G1_GGX_Schlick(float NoV, float eta) {
     k = k * k / 8.f;
     return 1.f / (NoV * (1.f - k) + k);
 }
-static inline float pow5(float x) { return powf(x, 5.f); }
+static inline float pow5(float x) {
+    if (g_mode == 1) { float x2 = x * x; return x2 * x2 * x; }
+    return powf(x, 5.f);
+}
 
 typedef struct { v3 wi; float pdf, g0, g1; } spec_sample;
 /* model/brdf.py:112-136 BaseBRDF.sample_specular */
@@ -647,6 +696,12 @@ ORC_API void orc_bake(const orc_scene *sc, const orc_emitter *em, const orc_slf 
         v3 x = v3_ld(pos + p * 3), n = v3_ld(nrm + p * 3);
         v3 w = specular ? v3_ld(wo + p * 3) : v3_make(0, 0, 0);
         double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+        /* mode 1: the kernels' reduction -- lane l accumulates samples l, l+L, l+2L, ... in f32 (L = lanes per pixel),
+           then an xor butterfly over the L lanes, then * (1.0f/spp) */
+        float lane0[64][3], lane1[64][3];
+        int L = 64;
+        if (spp < 64 && (spp & (spp - 1)) == 0) L = spp;
+        if (g_mode == 1) { memset(lane0, 0, sizeof(lane0)); memset(lane1, 0, sizeof(lane1)); }
         for (int s = 0; s < spp; ++s) {
             float u0, u1;
             if (u2) { u0 = u2[(p * spp + s) * 2]; u1 = u2[(p * spp + s) * 2 + 1]; }
@@ -663,10 +718,29 @@ ORC_API void orc_bake(const orc_scene *sc, const orc_emitter *em, const orc_slf 
             v3 pn = h.tri >= 0 ? hit_position(sc, &h) : v3_make(0, 0, 0);
             /* eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0) (bake_shading.py:121-122) */
             v3 Le = eval_emitter1(em, slf, pn, h.tri, 1, 1.0f, 0.0f, NULL, NULL);
-            if (specular) {
+            if (g_mode == 1) {
+                const int l = s % L;
+                if (specular) {
+                    lane0[l][0] += Le.x * g0; lane0[l][1] += Le.y * g0; lane0[l][2] += Le.z * g0;
+                    lane1[l][0] += Le.x * g1; lane1[l][1] += Le.y * g1; lane1[l][2] += Le.z * g1;
+                } else { lane0[l][0] += Le.x; lane0[l][1] += Le.y; lane0[l][2] += Le.z; }
+            } else if (specular) {
                 a0[0] += (double)(Le.x * g0); a0[1] += (double)(Le.y * g0); a0[2] += (double)(Le.z * g0);
                 a1[0] += (double)(Le.x * g1); a1[1] += (double)(Le.y * g1); a1[2] += (double)(Le.z * g1);
             } else { a0[0] += Le.x; a0[1] += Le.y; a0[2] += Le.z; }
+        }
+        if (g_mode == 1) {
+            for (int m = 1; m < L; m <<= 1) {
+                float t0[64][3], t1[64][3];
+                for (int l = 0; l < L; ++l) for (int c = 0; c < 3; ++c) { t0[l][c] = lane0[l][c] + lane0[l ^ m][c]; t1[l][c] = lane1[l][c] + lane1[l ^ m][c]; }
+                memcpy(lane0, t0, sizeof(float) * 3 * L); memcpy(lane1, t1, sizeof(float) * 3 * L);
+            }
+            const float inv_spp = 1.0f / (float)spp;
+            for (int c = 0; c < 3; ++c) {
+                out0[p * 3 + c] = lane0[0][c] * inv_spp;
+                if (specular && out1) out1[p * 3 + c] = lane1[0][c] * inv_spp;
+            }
+            continue;
         }
         /* .reshape(b,spp,3).mean(1): summation order of torch's reduction is unspecified; we accumulate in
            double and round once (differs from any f32 order by <= spp*2^-24 relative) */

@@ -43,6 +43,25 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def set_mode(mode):
+    """0 = literal restatement with libm (pinned to the goldens); 1 = the HIP kernels' exact arithmetic (see iris_oracle.c)."""
+    lib().orc_set_mode(C.c_int(int(mode)))
+
+
+def get_mode():
+    return int(lib().orc_get_mode())
+
+
+class device_arithmetic:
+    """with oracle.device_arithmetic(): ... -> oracle results comparable bit for bit with the GPU."""
+
+    def __enter__(self):
+        self.prev = get_mode(); set_mode(1)
+
+    def __exit__(self, *a):
+        set_mode(self.prev)
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 

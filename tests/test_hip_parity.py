@@ -80,9 +80,13 @@ def test_sample_diffuse(dev, oracle_mod):
     n = rng.normal(size=(1 << 18, 3)); n = (n / np.linalg.norm(n, axis=-1, keepdims=True)).astype(np.float32)
     u = rng.random((1 << 18, 2), dtype=np.float32)
     wi, pdf, _ = BaseBRDF().sample_diffuse(T(u, dev), T(n, dev))
-    owi, opdf, _ = oracle_mod.sample_diffuse(u, n)
+    owi, opdf, _ = oracle_mod.sample_diffuse(u, n)                # literal (libm) oracle: float tolerance
     np.testing.assert_allclose(N(wi), owi, atol=ATOL, rtol=0)
     np.testing.assert_allclose(N(pdf), opdf, atol=ATOL, rtol=0)
+    with oracle_mod.device_arithmetic():                          # same IEEE op sequence: bit for bit
+        owi, opdf, _ = oracle_mod.sample_diffuse(u, n)
+    np.testing.assert_array_equal(N(wi), owi)
+    np.testing.assert_array_equal(N(pdf), opdf)
 
 
 @pytest.mark.parametrize("r_idx", range(6))
@@ -92,6 +96,22 @@ def test_sample_specular(dev, r_idx):
     r = torch.tensor(g["roughness"][r_idx])
     out = BaseBRDF().sample_specular(T(g["u2"], dev), T(g["wo"], dev), T(g["normal"], dev), r)
     check_specular_outputs(r_idx, tuple(N(t) for t in out), g)
+
+
+@pytest.mark.parametrize("r_idx", range(6))
+def test_sample_specular_bit_exact_vs_oracle(dev, oracle_mod, r_idx):
+    from iris_amd.model.brdf import BaseBRDF
+    rng = np.random.default_rng(10 + r_idx)
+    B = 1 << 17
+    n = rng.normal(size=(B, 3)); n = (n / np.linalg.norm(n, axis=-1, keepdims=True)).astype(np.float32)
+    wo = n + rng.normal(size=(B, 3)); wo = (wo / np.linalg.norm(wo, axis=-1, keepdims=True)).astype(np.float32)
+    u = rng.random((B, 2), dtype=np.float32)
+    r = float(np.linspace(0.02, 1.0, 6, dtype=np.float32)[r_idx])
+    out = BaseBRDF().sample_specular(T(u, dev), T(wo, dev), T(n, dev), r)
+    with oracle_mod.device_arithmetic():
+        ref = oracle_mod.sample_specular(u, wo, n, r)
+    for a, b in zip(out, ref):
+        np.testing.assert_array_equal(N(a), b)
 
 
 def test_sample_empty_input(dev):
@@ -264,7 +284,7 @@ def test_bake_box_golden(dev, tmp_path):
     spp = int(g["spp"])
     Ld, tri = bs.bake_diffuse(sc, em, pos, nrm, spp, u2=T(g["u2_diffuse"], dev), want_tri=True)
     assert (N(tri) == g["tri_next_diffuse"]).mean() >= 0.9999
-    assert rel_l2(N(Ld), g["Ld"]) <= 1e-4
+    assert rel_l2(N(Ld), g["Ld"]) <= 1e-4          # the north-star bar, against the reference replay
     for r_idx, r in enumerate(g["roughness_level"]):
         Ls0, Ls1, tri = bs.bake_specular(sc, em, pos, nrm, wo, float(r), spp, u2=T(g[f"u2_spec_{r_idx}"], dev), want_tri=True)
         assert (N(tri) == g[f"tri_next_spec_{r_idx}"]).mean() >= 0.9995, r_idx
@@ -304,10 +324,15 @@ def test_bake_diffuse_vs_oracle(dev, oracle_mod, room_setup, spp):
     pos, nrm = s["pos"][:P], s["nrm"][:P]
     pix = (np.arange(P, dtype=np.int32) * 7 + 3)
     Ld, tri = bs.bake_diffuse(s["sc"], s["em"], T(pos, dev), T(nrm, dev), spp, seed=11, stream_id=0, pix_id=T(pix, dev), want_tri=True)
-    oLd, otri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=11, stream=0, pix_id=pix, want_tri=True)
-    assert (N(tri) == otri).mean() >= 0.9995
+    with oracle_mod.device_arithmetic():      # oracle restating the kernels' exact IEEE sequence: every bit must agree
+        oLd, otri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=11, stream=0, pix_id=pix, want_tri=True)
+    np.testing.assert_array_equal(N(tri), otri)
+    np.testing.assert_array_equal(N(Ld), oLd)
     assert (otri >= 0).all()
-    assert rel_l2(N(Ld), oLd) <= 1e-4
+    # literal (libm) oracle: agreement is statistical because the SLF / emitter lookups are discontinuous
+    lLd, ltri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=11, stream=0, pix_id=pix, want_tri=True)
+    assert (N(tri) == ltri).mean() >= 0.9995
+    assert rel_l2(N(Ld), lLd) <= 1e-3
 
 
 @pytest.mark.parametrize("r_idx", [0, 2, 5])
@@ -318,10 +343,14 @@ def test_bake_specular_vs_oracle(dev, oracle_mod, room_setup, r_idx):
     P, spp = 2000, 64
     pos, nrm, wo = s["pos"][:P], s["nrm"][:P], s["wo"][:P]
     Ls0, Ls1, tri = bs.bake_specular(s["sc"], s["em"], T(pos, dev), T(nrm, dev), T(wo, dev), rough, spp, seed=5, stream_id=1 + r_idx, want_tri=True)
-    o0, o1, otri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=rough, seed=5, stream=1 + r_idx, want_tri=True)
-    assert (N(tri) == otri).mean() >= 0.999
-    assert rel_l2(N(Ls0), o0) <= 1e-4
-    assert rel_l2(N(Ls1), o1) <= 1e-4
+    with oracle_mod.device_arithmetic():
+        o0, o1, otri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=rough, seed=5, stream=1 + r_idx, want_tri=True)
+    np.testing.assert_array_equal(N(tri), otri)
+    np.testing.assert_array_equal(N(Ls0), o0)
+    np.testing.assert_array_equal(N(Ls1), o1)
+    l0, l1, ltri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=rough, seed=5, stream=1 + r_idx, want_tri=True)
+    assert (N(tri) == ltri).mean() >= 0.999
+    assert rel_l2(N(Ls0), l0) <= 1e-3 and rel_l2(N(Ls1), l1) <= 1e-3
 
 
 def test_bake_properties_full_size(dev, room_setup):

@@ -6,7 +6,7 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if "bake_kernel" not in k and "trace" not in k and "intersect" not in k:
+            if "bake" not in k and "trace" not in k and "intersect" not in k:
                 continue
             k = k.split("(")[0][-60:]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
