@@ -353,6 +353,33 @@ def test_bake_specular_vs_oracle(dev, oracle_mod, room_setup, r_idx):
     assert rel_l2(N(Ls0), l0) <= 1e-3 and rel_l2(N(Ls1), l1) <= 1e-3
 
 
+def test_bake_cfg2_size_bit_exact_vs_oracle(dev, oracle_mod, room_setup):
+    """BASELINE.json configs[1] size (640x480 x SPP 64 = 19.7 M rays, diffuse lobe + one specular level on a quarter of
+    the pixels): every output bit equals the device-arithmetic oracle."""
+    from tools import synth
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.dataset import real_ldr
+    s = room_setup
+    H, W, spp = 480, 640, 64
+    K, c2w = synth.camera(H, W, 11)
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+    g = bs.primary_hits(s["sc"], xs, ds)
+    op, on, _, oidx, ovalid = s["osc"].ray_intersect(N(xs), N(ds))
+    np.testing.assert_array_equal(N(g["position"]), op[ovalid])
+    np.testing.assert_array_equal(N(g["normal"]), on[ovalid])
+    Ld = bs.bake_diffuse(s["sc"], s["em"], g["position"], g["normal"], spp, seed=21, pix_id=g["pix_id"])
+    pos, nrm, wo, pix = N(g["position"]), N(g["normal"]), N(g["wo"]), N(g["pix_id"])
+    with oracle_mod.device_arithmetic():
+        (oLd,) = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=21, stream=0, pix_id=pix)
+    np.testing.assert_array_equal(N(Ld), oLd)
+    q = slice(0, len(pos), 4)
+    a, b = bs.bake_specular(s["sc"], s["em"], g["position"][q], g["normal"][q], g["wo"][q], 0.608, spp, seed=21, stream_id=4, pix_id=g["pix_id"][q])
+    with oracle_mod.device_arithmetic():
+        oa, ob = oracle_mod.bake(s["osc"], s["oem"], pos[q], nrm[q], spp, wo=wo[q], roughness=np.float32(0.608), seed=21, stream=4, pix_id=pix[q])
+    np.testing.assert_array_equal(N(a), oa)
+    np.testing.assert_array_equal(N(b), ob)
+
+
 def test_bake_properties_full_size(dev, room_setup):
     """Size-independent properties at a size the oracle would not finish quickly (640x480 x spp 64 = 19.7 M rays):
     determinism (bit-identical reruns), shard invariance (any pixel subset with its pix_id reproduces the same rows
