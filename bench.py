@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--lobes", type=str, default="0,1,2,3,4,5,6", help="0 = diffuse, 1..6 = specular roughness levels")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pixel-block", type=int, default=8, help="order valid pixels in BxB image blocks (0 = row-major)")
     ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
     args = ap.parse_args()
 
@@ -104,7 +105,7 @@ def main():
         """One view: rays -> primary hits (this rank's stripes) -> 7 fused lobe kernels -> scatter -> one all_gather."""
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         xs, ds = xs[pix_local], ds[pix_local]
-        g = bs.primary_hits(scene, xs, ds, pixel_ids=pix_local)
+        g = bs.primary_hits(scene, xs, ds, pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
         P = g["position"].shape[0]
         maps = torch.zeros(n_maps, pix_local.numel(), 3, device=dev)
         m = 0
@@ -167,7 +168,7 @@ def main():
         avg_ms = float(np.mean(ms))
         # algorithmic bytes/ray: instrumented launch of the same kernel on every 16th pixel, all six roughness levels
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
-        g = bs.primary_hits(scene, xs[pix_local], ds[pix_local], pixel_ids=pix_local)
+        g = bs.primary_hits(scene, xs[pix_local], ds[pix_local], pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
         # every 16th block of 8192 consecutive pixels (whole tiles, so that the tile-sorted kernel sees its real coherence)
         nP = g["position"].shape[0]
         sel = torch.arange(nP, device=dev)

@@ -84,22 +84,33 @@ def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None,
     return (Ls0, Ls1, tri) if want_tri else (Ls0, Ls1)
 
 
-def primary_hits(scene, xs, ds, pixel_ids=None):
+def primary_hits(scene, xs, ds, pixel_ids=None, image_width=None, block=8):
     """bake_shading.py:98-101 / :154-157: primary closest hit + compaction to the valid pixels.
-    Returns dict(position, normal, wo, pix_id (int32 image-space pixel index), n_pixels)."""
+    Returns dict(position, normal, wo, pix_id (int32 image-space pixel index), sel, n_pixels).
+    image_width: when given, the valid pixels are ordered in `block` x `block` image blocks instead of row-major, so that the
+    consecutive pixels the bake kernels group into a tile are neighbours in 2-D (nearer origins, more coherent rays).  The
+    order of the pixel list changes neither the results (sample streams are keyed by pix_id) nor the caller's layout
+    (`sel` scatters the rows back)."""
     positions, normals, _, _, valid = ray_intersect(scene, xs, ds)
     sel = torch.nonzero(valid, as_tuple=False).reshape(-1)
     pix = sel if pixel_ids is None else pixel_ids[sel]
+    if image_width is not None and sel.numel() > 0:
+        y, x = pix // image_width, pix % image_width
+        nbx = (image_width + block - 1) // block
+        key = ((y // block) * nbx + x // block) * (block * block) + (y % block) * block + x % block
+        order = torch.argsort(key)
+        sel, pix = sel[order], pix[order]
     return {"position": positions[sel], "normal": normals[sel], "wo": -ds.reshape(-1, 3)[sel],
             "pix_id": pix.to(torch.int32), "sel": sel, "n_pixels": xs.shape[0]}
 
 
-def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=None, seed=0, pixel_ids=None, lobes=None):
+def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=None, seed=0, pixel_ids=None, lobes=None,
+              image_width=None):
     """One view: the primary pass once (the reference repeats it, :98 and :154), then the diffuse lobe and the six
     specular roughness levels.  Returns {'diffuse': (N,3), 'specular0': [6x (N,3)], 'specular1': [...], 'n_valid', 'rays'}
     with N = len(xs) rows in the caller's pixel order (zeros at invalid pixels, bake_shading.py:126-127)."""
     spps = list(SPPS_SPECULAR if spps_specular is None else spps_specular)
-    g = primary_hits(scene, xs, ds, pixel_ids)
+    g = primary_hits(scene, xs, ds, pixel_ids, image_width=image_width)
     N, dev = xs.shape[0], xs.device
     out = {"n_valid": int(g["sel"].shape[0]), "rays": 0, "specular0": [], "specular1": []}
     P = out["n_valid"]

@@ -20,7 +20,7 @@ struct BakeArgs {
     float* out0; float* out1; int64_t* tri_next;
     unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
     // v2 only
-    float* scratch;             // gridDim.x * kTileRays * (SPEC ? 6 : 3) floats
+    float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray results between trace and reduce
     unsigned int* tile_counter; // zeroed before the launch
     int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
 };
@@ -152,14 +152,6 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     return m;
 }
 
-template <bool SPEC>
-__device__ __forceinline__ f3 sample_direction(const BakeArgs& a, int64_t p, int s, f3 n, f3 w, f3 t, f3 b, uint64_t base) {
-    float u0, u1;
-    if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
-    else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
-    return SPEC ? specular_sampler(u0, u1, a.rough, w, n, t, b) : diffuse_sampler(u0, u1, n, t, b);
-}
-
 template <bool SPEC, bool COUNT>
 __global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
     // LDS: sorted ray list (16 KiB) + traversal stacks (24 KiB).  The stack region doubles as the sort's key / histogram
@@ -175,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
-    constexpr int NC = SPEC ? 6 : 3;
-    float* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
+    constexpr int NC = SPEC ? 2 : 1;  // float4 per ray
+    float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
     const int64_t n_tiles = (a.P + a.tile_px - 1) / a.tile_px;
     int lpp, ppw, rounds;
     reduce_geometry(spp, lpp, ppw, rounds);
@@ -200,11 +192,15 @@ __global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
         for (int r = tid; r < nr; r += kBlock) {
             const int pl = r / spp, s = r - pl * spp;
             const int64_t p = p0 + pl;
-            f3 n = ld3(a.nrm + p * 3), w = mk3(0.f, 0.f, 1.f), t, b;
-            if (SPEC) w = ld3(a.wo + p * 3);
-            normal_space(n, t, b);
+            const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
             const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
-            const uint32_t key = dir_bin(sample_direction<SPEC>(a, p, s, n, w, t, b, base));
+            f3 t, b;
+            normal_space(n, t, b);
+            float u0, u1;
+            if (a.u2) { const float* up = a.u2 + (p * spp + s) * 2; u0 = up[0]; u1 = up[1]; }
+            else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+            const f3 wi = SPEC ? specular_sampler(u0, u1, a.rough, w, n, t, b) : diffuse_sampler(u0, u1, n, t, b);
+            const uint32_t key = dir_bin(wi);
             s_keys[r] = (uint8_t)key;
             atomicAdd(&s_hist[key], 1u);
         }
@@ -236,14 +232,14 @@ __global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
                 const int r = s_sorted[i];
                 const int pl = r / spp, s = r - pl * spp;
                 const int64_t p = p0 + pl;
-                f3 x = ld3(a.pos + p * 3), n = ld3(a.nrm + p * 3), w = mk3(0.f, 0.f, 1.f), t, b;
-                if (SPEC) w = ld3(a.wo + p * 3);
-                normal_space(n, t, b);
+                const f3 x = ld3(a.pos + p * 3), n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
                 const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+                f3 t, b;
+                normal_space(n, t, b);
                 RayOut o = shade_sample<SPEC, COUNT, kTileStack>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
-                float* q = res + (size_t)r * NC;
-                q[0] = o.r0; q[1] = o.g0; q[2] = o.b0;
-                if (SPEC) { q[3] = o.r1; q[4] = o.g1; q[5] = o.b1; }
+                float4* q = res + (size_t)r * NC;
+                q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
+                if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
             }
         }
         // results were written by other waves of this workgroup, possibly to lines this CU's L1 still holds from the
@@ -261,9 +257,10 @@ __global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
             for (int rr = 0; rr < rounds; ++rr) {
                 const int s = rr * 64 + sl;
                 if (pvalid && s < spp) {
-                    const float* q = res + (size_t)(pl * spp + s) * NC;
-                    a0x += q[0]; a0y += q[1]; a0z += q[2];
-                    if (SPEC) { a1x += q[3]; a1y += q[4]; a1z += q[5]; }
+                    const float4* q = res + (size_t)(pl * spp + s) * NC;
+                    const float4 qa = q[0];
+                    a0x += qa.x; a0y += qa.y; a0z += qa.z;
+                    if (SPEC) { const float4 qb = q[1]; a1x += qa.w; a1y += qb.x; a1z += qb.y; }
                 }
             }
             for (int m = 1; m < lpp; m <<= 1) {

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -134,6 +135,8 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
     s->dev.tris = (const float4*)s->d_tris;
     s->dev.n_nodes = (int)nn;
     s->dev.n_tris = (int)nt;
+    s->dev.phase_min = kPhaseMin;
+    if (const char* e = getenv("IRIS_PHASE_MIN")) s->dev.phase_min = atoi(e);  // tuning knob (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
     s->info.node_bytes = 128; s->info.tri_bytes = 48; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
     s->info.sah_cost = bvh.sah_cost;
@@ -457,9 +460,10 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 static int bake_grid_blocks() { return num_cus() * 4; }  // 4 resident 256-thread workgroups per CU (VGPR- and LDS-bound)
 
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
-    (void)P;
-    if (spp < 1 || spp > kTileRays) return 0;  // v1 kernel only
-    return 256 + (uint64_t)bake_grid_blocks() * kTileRays * (specular ? 6 : 3) * sizeof(float);
+    if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
+    // [256 B counters][blocks x 8192 x (16|32) B per-ray results]
+    // (packing the pixel tensors into 48-B records was measured 7 % SLOWER than reading pos/nrm/wo directly: not done)
+    return 256 + (uint64_t)bake_grid_blocks() * kTileRays * (specular ? 2 : 1) * sizeof(float4);
 }
 
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
@@ -488,7 +492,7 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         if (tile_px < 1) tile_px = 1;
         a.tile_px = tile_px;
         a.tile_counter = (unsigned int*)workspace;
-        a.scratch = (float*)((char*)workspace + 256);
+        a.scratch = (float4*)((char*)workspace + 256);
         HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
         const int64_t n_tiles = (P + tile_px - 1) / tile_px;
         const int grid = (int)std::min<int64_t>(blocks, n_tiles);

@@ -17,6 +17,7 @@ struct SceneDev {
     const float4* tris;   // 3 x float4 = 48 B per leaf triangle: (p0.xyz,p1.x) (p1.yz,p2.xy) (p2.z, id, -, -)
     int n_nodes;
     int n_tris;
+    int phase_min;  // wave-level phase scheduling threshold (see trace_bvh4)
 };
 
 struct Hit {
@@ -85,6 +86,12 @@ __device__ __forceinline__ bool first_active_lane() {
     return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
 }
 
+// Wave-level phase scheduling.  A lane is in one of three states: at an internal node, at a leaf (k triangles tested so far),
+// or done.  The wave alternates a NODE phase and a LEAF phase; a phase ends when no lane needs it, or early when fewer than
+// kPhaseMin lanes still need it while at least kPhaseMin lanes wait for the other phase (stragglers are carried over instead of
+// keeping the whole wave in a nearly empty phase).  Per-lane results do not depend on the schedule.
+constexpr int kPhaseMin = 16;
+
 template <bool COUNT = false, int LDS_DEPTH = kStackLds>
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr) {
     Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
@@ -93,14 +100,22 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
     const bool px = ix >= 0.f, py = iy >= 0.f, pz = iz >= 0.f;
     Stack<LDS_DEPTH> st; st.lds = lds_stack; st.sp = 0;
     uint32_t cur = 0;  // root
-    while (cur != kEmptyRef) {
-        while (!(cur & kLeafBit)) {
-            if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
-            const float4* n = sc.nodes + (int64_t)cur * 8;
-            const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
-            const float4 rf = n[6];
-            float k0, k1, k2, k3;
-            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+    int k = 0;         // triangles of the current leaf already tested
+    const int kPhaseMinRt = sc.phase_min;
+    for (;;) {
+        // ---------------- node phase
+        for (;;) {
+            const bool at_node = cur != kEmptyRef && !(cur & kLeafBit);
+            const int n_node = __popcll(__ballot(at_node));
+            if (n_node == 0) break;
+            if (n_node < kPhaseMinRt && __popcll(__ballot(cur != kEmptyRef && (cur & kLeafBit))) >= kPhaseMinRt) break;
+            if (at_node) {
+                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
+                const float4* n = sc.nodes + (int64_t)cur * 8;
+                const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
+                const float4 rf = n[6];
+                float k0, k1, k2, k3;
+                uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
 #define IRIS_SLAB(K, C)                                                                                               \
     {                                                                                                                 \
         float tn = fmaxf(fmaxf(fmaf(px ? lox.C : hix.C, ix, nx), fmaf(py ? loy.C : hiy.C, iy, ny)),                   \
@@ -109,27 +124,33 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
                          fminf(fmaf(pz ? hiz.C : loz.C, iz, nz), h.t));                                               \
         K = tn <= tf ? tn : INFINITY;                                                                                 \
     }
-            IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
+                IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
 #undef IRIS_SLAB
-            IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
-            if (k0 < INFINITY) {
-                cur = r0;
-                if (k3 < INFINITY) st.push(r3);
-                if (k2 < INFINITY) st.push(r2);
-                if (k1 < INFINITY) st.push(r1);
-            } else {
-                cur = st.sp > 0 ? st.pop() : kEmptyRef;
+                IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
+                if (k0 < INFINITY) {
+                    cur = r0;
+                    if (k3 < INFINITY) st.push(r3);
+                    if (k2 < INFINITY) st.push(r2);
+                    if (k1 < INFINITY) st.push(r1);
+                } else {
+                    cur = st.sp > 0 ? st.pop() : kEmptyRef;
+                }
             }
-            if (cur == kEmptyRef) break;
         }
-        if (cur == kEmptyRef) break;
-        // leaf
-        const int start = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
-        for (int k = 0; k < cnt; ++k) {
-            if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
-            tri_test(sc, start + k, o, d, h);
+        // ---------------- leaf phase (one triangle per iteration)
+        for (;;) {
+            const bool at_leaf = cur != kEmptyRef && (cur & kLeafBit);
+            const int n_leaf = __popcll(__ballot(at_leaf));
+            if (n_leaf == 0) break;
+            if (n_leaf < kPhaseMinRt && __popcll(__ballot(cur != kEmptyRef && !(cur & kLeafBit))) >= kPhaseMinRt) break;
+            if (at_leaf) {
+                if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
+                const int start = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
+                tri_test(sc, start + k, o, d, h);
+                if (++k >= cnt) { k = 0; cur = st.sp > 0 ? st.pop() : kEmptyRef; }
+            }
         }
-        cur = st.sp > 0 ? st.pop() : kEmptyRef;
+        if (__ballot(cur != kEmptyRef) == 0) break;
     }
     return h;
 }
