@@ -129,3 +129,91 @@ def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=Non
         out["specular0"].append(scatter(a)); out["specular1"].append(scatter(b))
         out["rays"] += P * spps[r_idx]
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CLI: same flags and output files as the reference's bake_shading.py (:29-39, :131, :202-203)
+# ------------------------------------------------------------------------------------------------------------------
+def output_files(output, im_id):
+    d = [os.path.join(output, "diffuse", "{:03d}.exr".format(im_id))]
+    s = [os.path.join(output, "specular", "{:03d}_{}_{}.exr".format(im_id, k, r)) for r in range(N_ROUGHNESS) for k in (0, 1)]
+    return d + s
+
+
+def main(argv=None):
+    from argparse import ArgumentParser
+    from .model.emitter import SLFEmitter
+    from .utils import cameras, exr
+    from .utils.path_tracing import load_scene
+    parser = ArgumentParser(description="bake diffuse / specular shading maps (MI355X)")
+    parser.add_argument("--dataset_root", type=str, help="dataset root")
+    parser.add_argument("--scene", type=str, required=True, help="dataset folder")
+    parser.add_argument("--slf_path", type=str, required=True)
+    parser.add_argument("--emitter_path", type=str, required=True)
+    parser.add_argument("--output", type=str, required=True, help="output path")
+    parser.add_argument("--dataset", type=str, required=True, help="dataset type: synthetic | real | scannetpp | generic")
+    parser.add_argument("--ldr_img_dir", type=str, default=None)       # accepted for compatibility; bake never reads images
+    parser.add_argument("--res_scale", type=float, default=1.0)
+    # additions (defaults reproduce the reference)
+    parser.add_argument("--cameras", type=str, default=None, help="generic camera JSON (required for scannetpp: COLMAP I/O is out of scope)")
+    parser.add_argument("--img_hw", type=int, nargs=2, default=None)
+    parser.add_argument("--spp_diffuse", type=int, default=SPP_DIFFUSE)
+    parser.add_argument("--spps_specular", type=int, nargs=N_ROUGHNESS, default=SPPS_SPECULAR)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--compression", type=str, default="zip", choices=["none", "zips", "zip"])
+    parser.add_argument("--overwrite", action="store_true", help="re-bake views whose 13 files already exist")
+    args = parser.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise L.IrisError("bake_shading needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    if args.dataset in ("synthetic", "real"):
+        mesh_path = os.path.join(args.scene, "scene.obj")
+    elif args.dataset == "scannetpp":
+        mesh_path = os.path.join(args.dataset_root, "data", args.scene, "scans", "scene.ply")
+    else:
+        mesh_path = os.path.join(args.scene, "scene.obj") if os.path.exists(os.path.join(args.scene, "scene.obj")) else os.path.join(args.scene, "scene.ply")
+    assert os.path.exists(mesh_path), "mesh not found: " + mesh_path
+    scene = load_scene(mesh_path, device=device)
+
+    hw = tuple(args.img_hw) if args.img_hw else None
+    if args.cameras:
+        img_hw, views = cameras.load_generic(args.cameras, args.res_scale)
+    elif args.dataset == "synthetic":
+        img_hw, views = cameras.load_synthetic(args.scene, args.res_scale, hw)
+    elif args.dataset == "real":
+        img_hw, views = cameras.load_real(args.scene, args.res_scale, hw)
+    else:
+        raise L.IrisError("--dataset scannetpp needs --cameras cameras.json (COLMAP / nerfstudio parsing is dataset I/O outside this path)")
+
+    emitter = SLFEmitter(args.emitter_path, args.slf_path)
+    for p in emitter.parameters():
+        p.requires_grad = False
+    os.makedirs(os.path.join(args.output, "diffuse"), exist_ok=True)
+    os.makedirs(os.path.join(args.output, "specular"), exist_ok=True)
+
+    start_time = time.time()
+    rays = 0
+    for im_id in range(rank, len(views), world):           # views shard over ranks with no collective: one file set per view
+        files = output_files(args.output, im_id)
+        if not args.overwrite and all(os.path.exists(f) for f in files):
+            continue
+        xs, ds = cameras.view_rays(views[im_id], img_hw, device)
+        out = bake_view(scene, emitter, xs, ds, args.spp_diffuse, args.spps_specular, seed=args.seed, image_width=img_hw[1])
+        rays += out["rays"]
+        # pre-denoise maps: the OptiX AI denoiser of the reference (:129, :198-200) has no AMD counterpart
+        exr.write_exr(files[0], out["diffuse"].reshape(*img_hw, 3).cpu().numpy(), args.compression)
+        for r in range(N_ROUGHNESS):
+            exr.write_exr(files[1 + 2 * r], out["specular0"][r].reshape(*img_hw, 3).cpu().numpy(), args.compression)
+            exr.write_exr(files[2 + 2 * r], out["specular1"][r].reshape(*img_hw, 3).cpu().numpy(), args.compression)
+    torch.cuda.synchronize()
+    dt = time.time() - start_time
+    print("[bake_shading] rank {}: {} rays in {:.2f} s ({:.1f} Mrays/s incl. file I/O)".format(rank, rays, dt, rays / max(dt, 1e-9) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -566,13 +566,14 @@ ORC_API orc_scene *orc_scene_create(const float *verts, int64_t nv, const int32_
 }
 ORC_API void orc_scene_destroy(orc_scene *sc) { if (sc) { free(sc->nodes); free(sc->order); free(sc); } }
 
-static inline int slab(const orc_node *n, v3 o, v3 id, float tbest) {
+static inline int slab(const orc_node *n, v3 o, v3 id, float tbest, float *tnear) {
     float t0 = (n->lo[0] - o.x) * id.x, t1 = (n->hi[0] - o.x) * id.x;
     float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
     t0 = (n->lo[1] - o.y) * id.y; t1 = (n->hi[1] - o.y) * id.y;
     tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
     t0 = (n->lo[2] - o.z) * id.z; t1 = (n->hi[2] - o.z) * id.z;
     tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+    *tnear = tmin;
     /* conservative: a NaN slab (0*inf) is ignored by fmin/fmax; generous relative slack on both ends */
     return tmax >= 0.f && tmin <= tmax * 1.00001f + 1e-30f && tmin * 0.9999f <= tbest;
 }
@@ -580,24 +581,42 @@ static inline float safe_inv(float d) {
     if (fabsf(d) < 1e-30f) return d < 0.f || (d == 0.f && signbit(d)) ? -1e30f : 1e30f;
     return 1.0f / d;
 }
+/* ordered (near child first) stack traversal; only an accelerator for the brute-force semantics */
 static orc_hit intersect_bvh(const orc_scene *sc, v3 o, v3 d, int64_t *n_nodes, int64_t *n_tris) {
     orc_hit h = {INFINITY, 0.f, 0.f, -1};
     if (sc->nf == 0) return h;
     v3 id = v3_make(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    int32_t stack[128]; int sp = 0; stack[sp++] = 0;
-    while (sp) {
-        const orc_node *n = &sc->nodes[stack[--sp]];
-        if (n_nodes) ++*n_nodes;
-        if (!slab(n, o, id, h.t)) continue;
+    int32_t stack[128]; int sp = 0;
+    int32_t cur = 0; float tn;
+    if (n_nodes) ++*n_nodes;
+    if (!slab(&sc->nodes[0], o, id, h.t, &tn)) return h;
+    for (;;) {
+        const orc_node *n = &sc->nodes[cur];
         if (n->left < 0) {
             for (int32_t i = n->start; i < n->start + n->count; ++i) {
                 float t, u, v; int64_t f = sc->order[i];
                 if (n_tris) ++*n_tris;
                 if (tri_test(sc, f, o, d, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
             }
-        } else { stack[sp++] = n->start; stack[sp++] = n->left; }
+        } else {
+            float tl, tr;
+            if (n_nodes) *n_nodes += 2;
+            int hl = slab(&sc->nodes[n->left], o, id, h.t, &tl), hr = slab(&sc->nodes[n->start], o, id, h.t, &tr);
+            if (hl && hr) {
+                if (tl <= tr) { stack[sp++] = n->start; cur = n->left; } else { stack[sp++] = n->left; cur = n->start; }
+                continue;
+            }
+            if (hl) { cur = n->left; continue; }
+            if (hr) { cur = n->start; continue; }
+        }
+        /* pop; entries were valid when pushed, re-check against the current best */
+        for (;;) {
+            if (!sp) return h;
+            cur = stack[--sp];
+            if (n_nodes) ++*n_nodes;
+            if (slab(&sc->nodes[cur], o, id, h.t, &tn)) break;
+        }
     }
-    return h;
 }
 
 /* Mitsuba Mesh::compute_surface_interaction (restated): p = fma(p0,b0,fma(p1,b1,p2*b2)), b0 = 1-b1-b2 */

@@ -1,0 +1,98 @@
+"""EXR shading-cache files and the bake_shading CLI contract (reference: bake_shading.py:29-39,131,202-203)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+
+def test_exr_roundtrip(tmp_path):
+    from iris_amd.utils import exr
+    rng = np.random.default_rng(0)
+    img = (rng.random((37, 53, 3)) * 7).astype(np.float32)
+    img[0, 0] = [0.0, 1e-30, 65504.0]
+    for comp in ("none", "zips", "zip"):
+        p = str(tmp_path / f"a_{comp}.exr")
+        exr.write_exr(p, img, comp)
+        h = exr.read_exr_header(p)
+        assert [c for c, _ in h["channels"]] == ["B", "G", "R"] and h["height"] == 37 and h["width"] == 53
+        np.testing.assert_array_equal(exr.read_exr(p), img)        # float32 EXR is lossless
+    raw = open(str(tmp_path / "a_none.exr"), "rb").read()
+    assert raw[:4] == bytes([0x76, 0x2F, 0x31, 0x01])
+
+
+def test_output_file_names():
+    from iris_amd import bake_shading as bs
+    f = bs.output_files("out", 7)
+    assert f[0] == os.path.join("out", "diffuse", "007.exr")
+    assert f[1] == os.path.join("out", "specular", "007_0_0.exr") and f[2] == os.path.join("out", "specular", "007_1_0.exr")
+    assert f[-1] == os.path.join("out", "specular", "007_1_5.exr") and len(f) == 13
+
+
+def test_real_camera_loader(tmp_path):
+    """cam.txt (origin, lookat, up) -> OpenCV c2w exactly as utils/dataset/real_ldr.py:139-152."""
+    from iris_amd.utils import cameras
+    n = 12
+    rows, ks = [str(n)], [str(n)]
+    for i in range(n):
+        o = np.array([i * 0.1, 0.2, 0.3]); at = np.array([0.0, 1.0, 0.0]); up = np.array([0.0, 0.0, 1.0])
+        rows += [" ".join(map(str, o)), " ".join(map(str, o + at)), " ".join(map(str, up))]
+        ks += ["100 0 32", "0 100 24", "0 0 1"]
+    (tmp_path / "cam.txt").write_text("\n".join(rows)); (tmp_path / "K_list.txt").write_text("\n".join(ks))
+    hw, views = cameras.load_real(str(tmp_path), img_hw=(48, 64))
+    assert hw == (48, 64) and len(views) == n - 2            # views 0 and 10 are the validation split
+    c2w = views[0]["c2w"]
+    np.testing.assert_allclose(c2w[:, 2], [0, 1, 0], atol=1e-6)      # z = viewing direction
+    np.testing.assert_allclose(c2w[:, 1], [0, 0, -1], atol=1e-6)     # y = down
+    np.testing.assert_allclose(c2w[:, 3], [0.1, 0.2, 0.3], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_cli_synthetic_dataset(tmp_path):
+    """Tiny FIPT-style scene on disk -> CLI -> 13 EXR files per view == bake_view()."""
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils import exr, cameras
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.model.slf import VoxelSLF
+    from iris_amd.utils.path_tracing import load_scene
+    g = golden("bake_box.npz")
+    scene_dir = tmp_path / "scene"; (scene_dir / "train" / "Image").mkdir(parents=True)
+    with open(scene_dir / "scene.obj", "w") as fh:
+        for v in g["verts"]:
+            fh.write("v {} {} {}\n".format(*v))
+        for f in g["faces"]:
+            fh.write("f {} {} {}\n".format(*(f + 1)))
+    H, W = 20, 28
+    exr.write_exr(str(scene_dir / "train" / "Image" / "000_0001.exr"), np.zeros((H, W, 3), np.float32))
+    c2w = np.eye(4); c2w[:3, :4] = g["c2w"]; c2w[:3, 1:3] *= -1          # OpenCV -> the synthetic (x left, y up) convention is not
+    frames = [{"transform_matrix": c2w.tolist()}, {"transform_matrix": (c2w + np.eye(4) * 0).tolist()}]   # needed: any valid pose works
+    json.dump({"camera_angle_x": 1.2, "frames": frames}, open(scene_dir / "train" / "transforms.json", "w"))
+    slf = VoxelSLF(torch.from_numpy(g["slf_mask"]), float(g["voxel_min"]), float(g["voxel_max"]))
+    slf.radiance[:] = torch.from_numpy(g["slf_radiance"])
+    K = int(g["is_emitter"].sum())
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    torch.save({"is_emitter": torch.from_numpy(g["is_emitter"]), "emitter_vertices": torch.zeros(K, 3, 3), "emitter_area": torch.from_numpy(g["emitter_area"]),
+                "emitter_normal": torch.zeros(K, 3), "emitter_radiance": torch.from_numpy(g["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(g["slf_mask"]), "voxel_min": float(g["voxel_min"]), "voxel_max": float(g["voxel_max"]), "weight": slf.state_dict()}, sp)
+    out = str(tmp_path / "out")
+    argv = ["--scene", str(scene_dir), "--slf_path", sp, "--emitter_path", ep, "--output", out, "--dataset", "synthetic",
+            "--spp_diffuse", "16", "--spps_specular", "8", "8", "8", "8", "8", "8", "--seed", "3"]
+    bs.main(argv)
+    files = bs.output_files(out, 1)
+    assert all(os.path.exists(f) for f in files)
+    # same view through the library API
+    dev = torch.device("cuda:0")
+    img_hw, views = cameras.load_synthetic(str(scene_dir))
+    assert img_hw == (H, W)
+    xs, ds = cameras.view_rays(views[1], img_hw, dev)
+    ref = bs.bake_view(load_scene(str(scene_dir / "scene.obj"), device=dev), SLFEmitter(ep, sp), xs, ds, 16, [8] * 6, seed=3, image_width=W)
+    np.testing.assert_array_equal(exr.read_exr(files[0]), ref["diffuse"].reshape(H, W, 3).cpu().numpy())
+    np.testing.assert_array_equal(exr.read_exr(files[1 + 2 * 4]), ref["specular0"][4].reshape(H, W, 3).cpu().numpy())
+    np.testing.assert_array_equal(exr.read_exr(files[2 + 2 * 5]), ref["specular1"][5].reshape(H, W, 3).cpu().numpy())
+    assert float(ref["diffuse"].sum()) > 0
+    mt = os.path.getmtime(files[0])
+    bs.main(argv)                                                        # resume: nothing is re-baked
+    assert os.path.getmtime(files[0]) == mt
