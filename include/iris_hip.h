@@ -74,8 +74,10 @@ IRIS_API void iris_slf_destroy(iris_slf *);
 
 /* SLFEmitter.__init__ (model/emitter.py:149-173): is_emitter (nf) bool, radiance (n_rad,3) indexed by EMITTER
  * ORDINAL (model/emitter.py:203), area (k).  emitter_idx / emitter_pdf=1/k are derived here. */
+/* verts (k,3,3) = emitter_vertices and cdf (k) = emitter_cdf (model/emitter.py:155,170) are only needed by
+ * iris_sample_emitter / iris_pt_nee and may be NULL. */
 IRIS_API int iris_emitter_create(const uint8_t *is_emitter, int64_t nf, const float *radiance, int64_t n_rad, const float *area,
-                        int64_t k, int device, iris_emitter **out);
+                        int64_t k, const float *verts, const float *cdf, int device, iris_emitter **out);
 /* SLFEmitterLearn.radiance is a parameter (model/emitter.py:268): refresh the device copy from a DEVICE pointer. */
 IRIS_API int iris_emitter_set_radiance(iris_emitter *, const float *radiance_dev, int64_t n_rad, iris_stream_t);
 IRIS_API void iris_emitter_destroy(iris_emitter *);
@@ -133,6 +135,48 @@ IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const 
 
 /* ---- a10: lerp_specular (utils/ops.py:99-118): specular (B,R,3), roughness (B) -> (B,3) ------------------ */
 IRIS_API int iris_lerp_specular(const float *specular, const float *roughness, int64_t B, int R, float *out, iris_stream_t);
+
+/* ---- a9 (BASELINE cfg 5): path_tracing_single (utils/path_tracing.py:320-407) ------------------------------ */
+/* Building blocks of the call surface: */
+/* SLFEmitter.sample_emitter (model/emitter.py:224-255): s1 (N), s2 (N,2), position (N,3) -> wi (N,3), pdf (N), tri (N) */
+IRIS_API int iris_sample_emitter(const iris_emitter *, const float *s1, const float *s2, const float *position, int64_t N, float *wi,
+                        float *pdf, int64_t *tri, iris_stream_t);
+/* BaseBRDF.eval_brdf (model/brdf.py:138-175): albedo (N,3), roughness (N), metallic (N) -> brdf (N,3), pdf (N) */
+IRIS_API int iris_eval_brdf(const float *wi, const float *wo, const float *normal, const float *albedo, const float *roughness,
+                   const float *metallic, int64_t N, float *brdf, float *pdf, iris_stream_t);
+/* BaseBRDF.sample_brdf (model/brdf.py:177-210) -> wi (N,3), pdf (N), brdf/pdf weight (N,3) */
+IRIS_API int iris_sample_brdf(const float *s1, const float *s2, const float *wo, const float *normal, const float *albedo,
+                     const float *roughness, const float *metallic, int64_t N, float *wi, float *pdf, float *weight,
+                     iris_stream_t);
+/* Stages.  The material network is third party (tiny-cuda-nn) and is evaluated by the caller between them, exactly where
+ * the reference calls material_net (:355, :392).  L is linear in emitter.radiance, the only tensor that receives gradient:
+ * stages emit (emitter ordinal, rgb coefficient) pairs, accumulate_fwd gathers, accumulate_bwd scatter-adds. */
+/* :338-340  wi = normalize(rays_d + dx_du*(u-0.5) + dy_dv*(v-0.5)); dudv = the reference's torch.rand(2,B,spp,1) */
+IRIS_API int iris_pt_jitter(const float *rays_d, const float *dxdu, const float *dydv, const float *dudv, int64_t B, int spp, float *wi,
+                   iris_stream_t);
+/* :344  eval_emitter(position, wi, triangle_idx) with the radiance gather factored out: e0 = emitter ordinal or -1 */
+IRIS_API int iris_pt_primary_emit(const iris_emitter *, const int64_t *tri, int64_t N, int32_t *e0, uint8_t *valid_next, iris_stream_t);
+/* :357-382  emitter sampling + visibility ray + geometry term + eval_brdf + MIS -> term1 = coef1 * radiance[e1] */
+IRIS_API int iris_pt_nee(const iris_scene *, const iris_emitter *, const float *pos, const float *nrm, const float *wo, const float *albedo,
+                const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *coef1, int32_t *e1,
+                iris_stream_t);
+/* :384-391  sample_brdf + next intersection */
+IRIS_API int iris_pt_brdf_trace(const iris_scene *, const float *pos, const float *nrm, const float *wo, const float *albedo,
+                       const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *wi,
+                       float *pdf, float *weight, float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid,
+                       iris_stream_t);
+/* :394-404  eval_emitter(..., mat_next.roughness, 0.0) + geometry term + MIS -> term2 = coef2 * radiance[e2] + const2 */
+IRIS_API int iris_pt_brdf_finish(const iris_emitter *, const iris_slf *, const float *pos, const float *pos_next, const float *nrm_next,
+                        const float *wi, const int64_t *tri_next, const float *roughness_next, const float *pdf, const float *weight,
+                        int64_t N, float *coef2, float *const2, int32_t *e2, iris_stream_t);
+/* :406  L (B,3) = mean over spp; path_of (B*spp) maps a path to its row in the compacted stage arrays (or -1).
+ * radiance: the (n_rad,3) parameter tensor itself (model/emitter.py:268). */
+IRIS_API int iris_pt_accumulate_fwd(const float *radiance, const int32_t *e0, const int32_t *path_of, const int32_t *e1, const float *coef1,
+                           const int32_t *e2, const float *coef2, const float *const2, int64_t B, int spp, float *L,
+                           iris_stream_t);
+/* dL/d radiance: g_radiance (n_rad,3), zero-initialised by the caller, += scatter of gL (B,3) */
+IRIS_API int iris_pt_accumulate_bwd(const float *gL, const int32_t *e0, const int32_t *path_of, const int32_t *e1, const float *coef1,
+                           const int32_t *e2, const float *coef2, int64_t B, int spp, float *g_radiance, iris_stream_t);
 
 /* ---- misc --------------------------------------------------------------------------------------------- */
 /* Philox uniforms exactly as the bake kernels draw them (for tests): u2[i] = U(seed, idx0+i, stream_id). */

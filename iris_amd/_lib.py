@@ -30,7 +30,7 @@ PROTOTYPES = {
     "iris_scene_get_info": [_P, C.POINTER(SceneInfo)],
     "iris_slf_create": [_P, _I32, _P, _I64, _D, _D, _I32, C.POINTER(_P)],
     "iris_slf_destroy": [_P],
-    "iris_emitter_create": [_P, _I64, _P, _I64, _P, _I64, _I32, C.POINTER(_P)],
+    "iris_emitter_create": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, C.POINTER(_P)],
     "iris_emitter_set_radiance": [_P, _P, _I64, _P],
     "iris_emitter_destroy": [_P],
     "iris_raygen_real": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
@@ -45,6 +45,16 @@ PROTOTYPES = {
     "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
+    "iris_sample_emitter": [_P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "iris_eval_brdf": [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
+    "iris_sample_brdf": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "iris_pt_jitter": [_P, _P, _P, _P, _I64, _I32, _P, _P],
+    "iris_pt_primary_emit": [_P, _P, _I64, _P, _P, _P],
+    "iris_pt_nee": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
+    "iris_pt_brdf_trace": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
+    "iris_pt_brdf_finish": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "iris_pt_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
+    "iris_pt_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
     "iris_last_error": [],
     "iris_version": [],
 }

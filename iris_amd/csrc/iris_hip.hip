@@ -14,6 +14,7 @@
 #include "iris_device.h"
 #include "iris_trace.h"
 #include "iris_bake.h"
+#include "iris_pt.h"
 
 using namespace iris;
 
@@ -59,6 +60,11 @@ struct iris_emitter {
     void* d_ord = nullptr;
     void* d_rad = nullptr;
     void* d_area = nullptr;
+    void* d_verts = nullptr;   // (K,3,3) emitter_vertices   (sample_emitter only)
+    void* d_cdf = nullptr;     // (K) emitter_cdf
+    void* d_ord2tri = nullptr; // (K) triangle index per emitter ordinal
+    EmitSampleDev sample{};
+    bool can_sample = false;
     int64_t n_rad = 0, k = 0;
 };
 
@@ -190,7 +196,7 @@ extern "C" IRIS_API void iris_slf_destroy(iris_slf* s) {
 }
 
 extern "C" IRIS_API int iris_emitter_create(const uint8_t* is_emitter, int64_t nf, const float* radiance, int64_t n_rad, const float* area,
-                                   int64_t k, int device, iris_emitter** out) {
+                                   int64_t k, const float* verts, const float* cdf, int device, iris_emitter** out) {
     API_BEGIN
     if (!out || nf < 0 || k < 0 || n_rad < 0 || (nf > 0 && !is_emitter)) return fail(IRIS_ERR_ARG, "iris_emitter_create: bad arguments");
     HIP_TRY(hipSetDevice(device));
@@ -213,6 +219,19 @@ extern "C" IRIS_API int iris_emitter_create(const uint8_t* is_emitter, int64_t n
     e->dev.nf = nf;
     float kf = (float)k; if (kf < 1e-12f) kf = 1e-12f;  // NF.normalize(ones(k), p=1)
     e->dev.emitter_pdf = 1.0f / kf;
+    if (verts && cdf && k > 0) {                          // tables of sample_emitter (model/emitter.py:224-255)
+        std::vector<int32_t> o2t((size_t)k);
+        for (int64_t i = 0; i < nf; ++i) if (ord[(size_t)i] >= 0) o2t[(size_t)ord[(size_t)i]] = (int32_t)i;
+        HIP_TRY(hipMalloc(&e->d_verts, (size_t)k * 36));
+        HIP_TRY(hipMalloc(&e->d_cdf, (size_t)k * 4));
+        HIP_TRY(hipMalloc(&e->d_ord2tri, (size_t)k * 4));
+        HIP_TRY(hipMemcpy(e->d_verts, verts, (size_t)k * 36, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_cdf, cdf, (size_t)k * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_ord2tri, o2t.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+        e->sample.cdf = (const float*)e->d_cdf; e->sample.verts = (const float*)e->d_verts; e->sample.area = (const float*)e->d_area;
+        e->sample.ord2tri = (const int32_t*)e->d_ord2tri; e->sample.k = k; e->sample.emitter_pdf = e->dev.emitter_pdf;
+        e->can_sample = true;
+    }
     *out = e;
     return IRIS_OK;
     API_END
@@ -220,6 +239,7 @@ extern "C" IRIS_API int iris_emitter_create(const uint8_t* is_emitter, int64_t n
 extern "C" IRIS_API void iris_emitter_destroy(iris_emitter* e) {
     if (!e) return;
     (void)hipFree(e->d_ord); (void)hipFree(e->d_rad); (void)hipFree(e->d_area);
+    (void)hipFree(e->d_verts); (void)hipFree(e->d_cdf); (void)hipFree(e->d_ord2tri);
     delete e;
 }
 
@@ -531,4 +551,117 @@ extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emit
                                   uint64_t* stats, int variant, void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
     return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stats, variant,
                        workspace, workspace_bytes, stream);
+}
+
+// ======================================================================================================
+// a9 (cfg 5): path_tracing_single building blocks and stages (iris_pt.h)
+// ======================================================================================================
+#define LAUNCH1D(kernel, n, st, ...)                                                                          \
+    do {                                                                                                      \
+        hipLaunchKernelGGL(kernel, dim3(grid_for((n), 256, 8192)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
+        HIP_TRY(hipGetLastError());                                                                           \
+    } while (0)
+
+extern "C" IRIS_API int iris_sample_emitter(const iris_emitter* e, const float* s1, const float* s2, const float* position, int64_t N, float* wi,
+                                   float* pdf, int64_t* tri, iris_stream_t stream) {
+    if (!e || !e->can_sample) return fail(IRIS_ERR_ARG, "iris_sample_emitter: emitter was created without vertices / cdf");
+    if (N < 0 || (N > 0 && (!s1 || !s2 || !position || !wi || !pdf || !tri))) return fail(IRIS_ERR_ARG, "iris_sample_emitter: bad arguments");
+    if (N == 0) return IRIS_OK;
+    LAUNCH1D(sample_emitter_kernel, N, stream, e->sample, s1, s2, position, N, wi, pdf, tri);
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_eval_brdf(const float* wi, const float* wo, const float* normal, const float* albedo, const float* roughness,
+                              const float* metallic, int64_t N, float* brdf, float* pdf, iris_stream_t stream) {
+    if (N < 0 || (N > 0 && (!wi || !wo || !normal || !albedo || !roughness || !metallic || !brdf || !pdf))) return fail(IRIS_ERR_ARG, "iris_eval_brdf: bad arguments");
+    if (N == 0) return IRIS_OK;
+    LAUNCH1D(eval_brdf_kernel, N, stream, wi, wo, normal, albedo, roughness, metallic, N, brdf, pdf);
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_sample_brdf(const float* s1, const float* s2, const float* wo, const float* normal, const float* albedo,
+                                const float* roughness, const float* metallic, int64_t N, float* wi, float* pdf, float* weight,
+                                iris_stream_t stream) {
+    if (N < 0 || (N > 0 && (!s1 || !s2 || !wo || !normal || !albedo || !roughness || !metallic || !wi || !pdf || !weight)))
+        return fail(IRIS_ERR_ARG, "iris_sample_brdf: bad arguments");
+    if (N == 0) return IRIS_OK;
+    LAUNCH1D(sample_brdf_kernel, N, stream, s1, s2, wo, normal, albedo, roughness, metallic, N, wi, pdf, weight);
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_pt_jitter(const float* rays_d, const float* dxdu, const float* dydv, const float* dudv, int64_t B, int spp, float* wi,
+                              iris_stream_t stream) {
+    if (B < 0 || spp < 1 || (B > 0 && (!rays_d || !dxdu || !dydv || !dudv || !wi))) return fail(IRIS_ERR_ARG, "iris_pt_jitter: bad arguments");
+    if (B == 0) return IRIS_OK;
+    LAUNCH1D(pt_jitter_kernel, B * spp, stream, rays_d, dxdu, dydv, dudv, B, spp, wi);
+    return IRIS_OK;
+}
+__global__ void pt_primary_emit_kernel(EmitDev e, const int64_t* __restrict__ tri, int64_t N, int32_t* __restrict__ e0, uint8_t* __restrict__ valid_next) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool vis = tri[i] != -1;
+        const int ord = vis ? e.emit_ord[tri[i]] : -1;
+        e0[i] = ord;
+        valid_next[i] = (vis && ord < 0) ? 1 : 0;
+    }
+}
+extern "C" IRIS_API int iris_pt_primary_emit(const iris_emitter* e, const int64_t* tri, int64_t N, int32_t* e0, uint8_t* valid_next, iris_stream_t stream) {
+    if (!e || N < 0 || (N > 0 && (!tri || !e0 || !valid_next))) return fail(IRIS_ERR_ARG, "iris_pt_primary_emit: bad arguments");
+    if (N == 0) return IRIS_OK;
+    LAUNCH1D(pt_primary_emit_kernel, N, stream, e->dev, tri, N, e0, valid_next);
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e, const float* pos, const float* nrm, const float* wo, const float* albedo,
+                           const float* roughness, const float* metallic, const float* s1, const float* s2, int64_t N, float* coef1, int32_t* e1,
+                           iris_stream_t stream) {
+    if (!sc || !e || !e->can_sample) return fail(IRIS_ERR_ARG, "iris_pt_nee: scene / emitter (with vertices + cdf) required");
+    if (N < 0 || (N > 0 && (!pos || !nrm || !wo || !albedo || !roughness || !metallic || !s1 || !s2 || !coef1 || !e1))) return fail(IRIS_ERR_ARG, "iris_pt_nee: bad arguments");
+    if (N == 0) return IRIS_OK;
+    PtArgs a{};
+    a.sc = sc->dev; a.em = e->dev; a.es = e->sample; a.N = N;
+    a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
+    a.coef1 = coef1; a.e1 = e1;
+    hipLaunchKernelGGL(pt_nee_kernel, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* pos, const float* nrm, const float* wo, const float* albedo,
+                                  const float* roughness, const float* metallic, const float* s1, const float* s2, int64_t N, float* wi,
+                                  float* pdf, float* weight, float* pos_next, float* nrm_next, int64_t* tri_next, uint8_t* valid,
+                                  iris_stream_t stream) {
+    if (!sc || N < 0 || (N > 0 && (!pos || !nrm || !wo || !albedo || !roughness || !metallic || !s1 || !s2 || !wi || !pdf || !weight || !pos_next ||
+                                   !nrm_next || !tri_next || !valid)))
+        return fail(IRIS_ERR_ARG, "iris_pt_brdf_trace: bad arguments");
+    if (N == 0) return IRIS_OK;
+    PtArgs a{};
+    a.sc = sc->dev; a.N = N;
+    a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
+    a.wi_out = wi; a.brdf_pdf = pdf; a.brdf_w = weight; a.pos_next = pos_next; a.nrm_next = nrm_next; a.tri_next = tri_next; a.valid_next_hit = valid;
+    hipLaunchKernelGGL(pt_brdf_trace_kernel, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_pt_brdf_finish(const iris_emitter* e, const iris_slf* slf, const float* pos, const float* pos_next, const float* nrm_next,
+                                   const float* wi, const int64_t* tri_next, const float* roughness_next, const float* pdf, const float* weight,
+                                   int64_t N, float* coef2, float* const2, int32_t* e2, iris_stream_t stream) {
+    if (!e || !slf || N < 0 || (N > 0 && (!pos || !pos_next || !nrm_next || !wi || !tri_next || !roughness_next || !pdf || !weight || !coef2 || !const2 || !e2)))
+        return fail(IRIS_ERR_ARG, "iris_pt_brdf_finish: bad arguments");
+    if (N == 0) return IRIS_OK;
+    PtArgs a{};
+    a.em = e->dev; a.slf = slf->dev; a.N = N;
+    a.pos = pos; a.pos_n_in = pos_next; a.nrm_n_in = nrm_next; a.wi_in = wi; a.tri_n_in = tri_next; a.rough_next = roughness_next; a.pdf_in = pdf; a.w_in = weight;
+    a.coef2 = coef2; a.const2 = const2; a.e2 = e2;
+    LAUNCH1D(pt_brdf_finish_kernel, N, stream, a);
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_pt_accumulate_fwd(const float* radiance, const int32_t* e0, const int32_t* path_of, const int32_t* e1, const float* coef1,
+                                      const int32_t* e2, const float* coef2, const float* const2, int64_t B, int spp, float* L,
+                                      iris_stream_t stream) {
+    if (B < 0 || spp < 1 || (B > 0 && (!radiance || !e0 || !path_of || !L))) return fail(IRIS_ERR_ARG, "iris_pt_accumulate_fwd: bad arguments");
+    if (B == 0) return IRIS_OK;
+    LAUNCH1D(pt_accumulate_fwd_kernel, B, stream, radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp, L);
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_pt_accumulate_bwd(const float* gL, const int32_t* e0, const int32_t* path_of, const int32_t* e1, const float* coef1,
+                                      const int32_t* e2, const float* coef2, int64_t B, int spp, float* g_radiance, iris_stream_t stream) {
+    if (B < 0 || spp < 1 || (B > 0 && (!gL || !e0 || !path_of || !g_radiance))) return fail(IRIS_ERR_ARG, "iris_pt_accumulate_bwd: bad arguments");
+    if (B == 0) return IRIS_OK;
+    LAUNCH1D(pt_accumulate_bwd_kernel, B * spp, stream, gL, e0, path_of, e1, coef1, e2, coef2, B, spp, g_radiance);
+    return IRIS_OK;
 }

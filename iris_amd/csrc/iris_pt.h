@@ -1,0 +1,283 @@
+// cfg 5: the one-bounce MIS path tracer the reference back-propagates through
+// (utils/path_tracing.py:320-407 path_tracing_single), with its building blocks SLFEmitter.sample_emitter
+// (model/emitter.py:224-255), BaseBRDF.eval_brdf / sample_brdf (model/brdf.py:138-210).
+//
+// The material network (NGPBRDF, tiny-cuda-nn: third party) is evaluated by the caller between the stages, so the path is
+// staged exactly where the reference calls material_net: jitter -> [ray_intersect, primary emitter] -> material ->
+// {NEE stage, BRDF-sample stage} -> material -> finish stage -> accumulate.  Only emitter.radiance receives gradient
+// (SURVEY.md section 3.4), and L is linear in it: every stage emits (emitter ordinal, rgb coefficient) pairs; the forward
+// pass is a gather, the backward pass the matching scatter-add.
+#pragma once
+#include "iris_trace.h"
+
+namespace iris {
+
+struct EmitSampleDev {
+    const float* cdf;       // (K) emitter_cdf exactly as torch computed it (model/emitter.py:170)
+    const float* verts;     // (K,3,3) emitter_vertices
+    const float* area;      // (K)
+    const int32_t* ord2tri; // (K) triangle index of emitter ordinal (model/emitter.py:165-166)
+    int64_t k;
+    float emitter_pdf;      // 1/K
+};
+
+struct Mat { f3 albedo; float rough, metal; };
+
+// model/brdf.py:138-175 eval_brdf
+__device__ __forceinline__ void eval_brdf1(f3 wi, f3 wo, f3 n, Mat m, f3& brdf, float& pdf) {
+    f3 h = t_normalize(mk3(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z));
+    float NoL = relu(t_dot(wi, n)), NoV = relu(t_dot(wo, n));
+    float VoH = relu(t_dot(wo, h)), NoH = relu(t_dot(n, h));
+    float D = D_GGX(NoH, m.rough);
+    float pdf_spec = D / (4.f * fmaxf(VoH, 1e-4f)) * NoH;
+    float pdf_diff = NoL / kPi;
+    pdf = 0.5f * pdf_spec + 0.5f * pdf_diff;
+    float om = 1.f - m.metal;
+    f3 kd = mk3(m.albedo.x * om, m.albedo.y * om, m.albedo.z * om);
+    f3 ks = mk3(0.04f * om + m.albedo.x * m.metal, 0.04f * om + m.albedo.y * m.metal, 0.04f * om + m.albedo.z * m.metal);
+    float G = G1_GGX_Schlick(NoL, m.rough) * G1_GGX_Schlick(NoV, m.rough);   // G_Smith(NoV,NoL,r) = g1_l*g1_v
+    float x1 = 1.f - VoH, x2 = x1 * x1, x = x2 * x2 * x1;                     // (1-VoH).pow(5)
+    // fresnelSchlick(VoH,F0) = F0 + (1-F0)*x ; brdf_spec = D*G*F/4.0*NoL ; brdf_diff = kd/pi*NoL
+    float dg = D * G;
+    brdf.x = kd.x / kPi * NoL + dg * (ks.x + (1.f - ks.x) * x) / 4.0f * NoL;
+    brdf.y = kd.y / kPi * NoL + dg * (ks.y + (1.f - ks.y) * x) / 4.0f * NoL;
+    brdf.z = kd.z / kPi * NoL + dg * (ks.z + (1.f - ks.z) * x) / 4.0f * NoL;
+}
+
+// model/brdf.py:177-210 sample_brdf
+__device__ __forceinline__ void sample_brdf1(float s1, float u0, float u1, f3 wo, f3 n, Mat m, f3& wi, float& pdf, f3& weight) {
+    f3 t, b;
+    normal_space(n, t, b);
+    wi = (s1 > 0.5f) ? diffuse_sampler(u0, u1, n, t, b) : specular_sampler(u0, u1, m.rough, wo, n, t, b);
+    f3 brdf;
+    eval_brdf1(wi, wo, n, m, brdf, pdf);
+    // torch.where(pdf>0, brdf/pdf, 0); NaN -> 0
+    weight = mk3(0.f, 0.f, 0.f);
+    if (pdf > 0.f) {
+        weight = mk3(brdf.x / pdf, brdf.y / pdf, brdf.z / pdf);
+        if (weight.x != weight.x) weight.x = 0.f;
+        if (weight.y != weight.y) weight.y = 0.f;
+        if (weight.z != weight.z) weight.z = 0.f;
+    }
+}
+
+// model/emitter.py:224-255 sample_emitter
+__device__ __forceinline__ void sample_emitter1(const EmitSampleDev& e, float s1, float u0, float u1, f3 pos, f3& wi, float& pdf, int64_t& tri) {
+    const float v = fmaxf(s1, 1e-12f);
+    int64_t lo = 0, hi = e.k;                     // torch.searchsorted(cdf, v): first i with cdf[i] >= v
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (e.cdf[mid] < v) lo = mid + 1; else hi = mid; }
+    const int64_t ei = lo < e.k ? lo : e.k - 1;    // the reference would index out of range when v > cdf[-1]; clamp
+    const float xi1 = sqrtf(u0);
+    const float u = 1.f - xi1, vv = xi1 * u1, w = (1.f - u) - vv;
+    const float* p = e.verts + ei * 9;
+    f3 p1 = mk3((p[0] * u + p[3] * vv) + p[6] * w, (p[1] * u + p[4] * vv) + p[7] * w, (p[2] * u + p[5] * vv) + p[8] * w);
+    wi = t_normalize(sub3(p1, pos));
+    pdf = e.emitter_pdf / fmaxf(e.area[ei], 1e-12f);
+    tri = e.ord2tri[ei];
+}
+
+// utils/path_tracing.py:338-340: wi = normalize(rays_d + dx_du*du + dy_dv*dv), du,dv = rand - 0.5
+__global__ void pt_jitter_kernel(const float* __restrict__ rays_d, const float* __restrict__ dxdu, const float* __restrict__ dydv,
+                                 const float* __restrict__ dudv /* (2,B,spp) */, int64_t B, int spp, float* __restrict__ wi) {
+    const int64_t n = B * spp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / spp;
+        const float du = dudv[i] - 0.5f, dv = dudv[n + i] - 0.5f;
+        f3 d = ld3(rays_d + b * 3), dx = ld3(dxdu + b * 3), dy = ld3(dydv + b * 3);
+        st3(wi + i * 3, t_normalize(mk3((d.x + dx.x * du) + dy.x * dv, (d.y + dx.y * du) + dy.y * dv, (d.z + dx.z * du) + dy.z * dv)));
+    }
+}
+
+struct PtArgs {
+    SceneDev sc; EmitDev em; SlfDev slf; EmitSampleDev es;
+    int64_t N;
+    const float *pos, *nrm, *wo, *albedo, *rough, *metal;   // (N,3),(N,3),(N,3),(N,3),(N),(N)
+    const float *s1, *s2;                                    // (N),(N,2) uniforms
+    // NEE outputs
+    float* coef1; int32_t* e1;
+    // BRDF-sample outputs
+    float *wi_out, *brdf_pdf, *brdf_w, *pos_next, *nrm_next; int64_t* tri_next; uint8_t* valid_next_hit;
+    // finish inputs/outputs
+    const float *wi_in, *pdf_in, *w_in, *pos_n_in, *nrm_n_in, *rough_next; const int64_t* tri_n_in;
+    float *coef2, *const2; int32_t* e2;
+};
+
+__device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
+    Mat m; m.albedo = ld3(a.albedo + i * 3); m.rough = a.rough[i]; m.metal = a.metal[i];
+    return m;
+}
+
+// utils/path_tracing.py:357-382: emitter sampling, visibility ray, geometry term, eval_brdf, power-2 MIS.
+// term1 = coef1 * radiance[e1]   (e1 = -1 -> no contribution)
+__global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
+        const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
+        f3 wi; float emit_pdf; int64_t emit_tri;
+        sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], x, wi, emit_pdf, emit_tri);
+        const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
+        Hit h = trace_bvh4(a.sc, o, wi, s_stack + threadIdx.x);
+        const bool emit_valid = h.slot >= 0;
+        int ord = -1;
+        float G = 1.f;
+        bool emit_vis = true;                                    // (~emit_valid) | (emit_triangle_idx == triangle_idx)
+        if (emit_valid) {
+            f3 p0, p1, p2;
+            hit_vertices(a.sc, h, p0, p1, p2);
+            const f3 ep = hit_position(h, p0, p1, p2);
+            f3 en = t_normalize(hit_normal(p0, p1, p2));
+            if (t_dot(en, mk3(-wi.x, -wi.y, -wi.z)) < 0.f) en = mk3(-en.x, -en.y, -en.z);
+            emit_vis = emit_tri == (int64_t)h.id;
+            ord = a.em.emit_ord[h.id];                           // eval_emitter(emit_position, wi, triangle_idx): Le = radiance[ord] if emitter
+            const f3 dlt = sub3(ep, x);
+            const float d2 = (dlt.x * dlt.x + dlt.y * dlt.y) + dlt.z * dlt.z;
+            G = fabsf(t_dot(mk3(-wi.x, -wi.y, -wi.z), en)) / fmaxf(d2, 1e-6f);
+        }
+        f3 brdf; float brdf_pdf;
+        eval_brdf1(wi, wo, n, load_mat(a, i), brdf, brdf_pdf);
+        brdf_pdf = brdf_pdf * G;
+        float w_mis = 0.f;
+        if (emit_pdf > 0.f && !isinf(brdf_pdf)) w_mis = emit_pdf * emit_pdf / fmaxf(emit_pdf * emit_pdf + brdf_pdf * brdf_pdf, 1e-6f);
+        if (isinf(emit_pdf) || brdf_pdf == 0.f) w_mis = 1.f;
+        // emit_weight = Le * emit_vis * G / clamp(emit_pdf,1e-6); L += emit_brdf * emit_weight * w_mis
+        const float s = (emit_vis ? 1.f : 0.f);
+        const float ew = G / fmaxf(emit_pdf, 1e-6f);
+        // coefficient applied to radiance[ord]: ((1*vis)*G/pdf) then *brdf then *w_mis, in the reference's evaluation order
+        st3(a.coef1 + i * 3, mk3(brdf.x * (s * ew) * w_mis, brdf.y * (s * ew) * w_mis, brdf.z * (s * ew) * w_mis));
+        a.e1[i] = (emit_valid && ord >= 0) ? ord : -1;
+    }
+}
+
+// utils/path_tracing.py:384-392: BRDF sampling + next intersection
+__global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
+        const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
+        f3 wi, w; float pdf;
+        sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
+        const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
+        Hit h = trace_bvh4(a.sc, o, wi, s_stack + threadIdx.x);
+        f3 pn = mk3(0.f, 0.f, 0.f), nn = mk3(0.f, 0.f, 0.f);
+        int64_t tri = -1;
+        if (h.slot >= 0) {
+            f3 p0, p1, p2;
+            hit_vertices(a.sc, h, p0, p1, p2);
+            pn = hit_position(h, p0, p1, p2);
+            nn = t_normalize(hit_normal(p0, p1, p2));
+            if (t_dot(nn, mk3(-wi.x, -wi.y, -wi.z)) < 0.f) nn = mk3(-nn.x, -nn.y, -nn.z);
+            tri = h.id;
+        }
+        st3(a.wi_out + i * 3, wi); a.brdf_pdf[i] = pdf; st3(a.brdf_w + i * 3, w);
+        st3(a.pos_next + i * 3, pn); st3(a.nrm_next + i * 3, nn); a.tri_next[i] = tri; a.valid_next_hit[i] = h.slot >= 0;
+    }
+}
+
+// utils/path_tracing.py:394-404: eval_emitter at the BRDF-sampled hit, geometry term, MIS.
+// term2 = coef2 * radiance[e2] + const2   (const2 = coef2 * SLF radiance)
+__global__ void pt_brdf_finish_kernel(PtArgs a) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * blockDim.x) {
+        const f3 x = ld3(a.pos + i * 3), pn = ld3(a.pos_n_in + i * 3), nn = ld3(a.nrm_n_in + i * 3), wi = ld3(a.wi_in + i * 3);
+        const int64_t tri = a.tri_n_in[i];
+        // eval_emitter(position_next, wi, triangle_idx, mat_next['roughness'], trace_roughness=0.0), radiance factored out
+        const bool vis = tri != -1;
+        int ord = -1;
+        if (vis) ord = a.em.emit_ord[tri];
+        const bool is_area = ord >= 0;
+        float emit_pdf = 0.f;
+        if (is_area) emit_pdf = a.em.emitter_pdf / fmaxf(a.em.area[ord], 1e-12f);
+        bool valid_next = (!is_area) && vis;
+        f3 slf = mk3(0.f, 0.f, 0.f);
+        if ((!is_area) && vis && a.rough_next[i] > 0.0f) {
+            slf = slf_forward(a.slf, pn);
+            if ((slf.x + slf.y) + slf.z > 0.f) valid_next = false;
+        }
+        const f3 dlt = sub3(x, pn);
+        const float d2 = (dlt.x * dlt.x + dlt.y * dlt.y) + dlt.z * dlt.z;
+        float G = fabsf(t_dot(mk3(-nn.x, -nn.y, -nn.z), wi)) / fmaxf(d2, 1e-6f);
+        if (!valid_next) G = 1.f;                                 // torch.where(valid_next, G, 1)
+        const float brdf_pdf = a.pdf_in[i] * G;
+        float w_mis = 0.f;
+        if (brdf_pdf > 0.f && !isinf(emit_pdf)) w_mis = brdf_pdf * brdf_pdf / (emit_pdf * emit_pdf + brdf_pdf * brdf_pdf);
+        if (isinf(brdf_pdf) || emit_pdf == 0.f) w_mis = 1.f;
+        const f3 w = ld3(a.w_in + i * 3);
+        // L += brdf_weight * Le * w_mis with Le = radiance[ord] (area) + slf (diffuse cache)
+        st3(a.coef2 + i * 3, mk3(w.x * w_mis, w.y * w_mis, w.z * w_mis));
+        st3(a.const2 + i * 3, mk3(w.x * slf.x * w_mis, w.y * slf.y * w_mis, w.z * slf.z * w_mis));
+        a.e2[i] = is_area ? ord : -1;
+    }
+}
+
+// L[b] = mean_s( radiance[e0] + [active] (coef1*radiance[e1] + (coef2*radiance[e2] + const2)) )   (utils/path_tracing.py:344,382,404,406)
+// path_of: (B*spp) int32 index into the compacted arrays or -1.
+__global__ void pt_accumulate_fwd_kernel(const float* __restrict__ radiance, const int32_t* __restrict__ e0, const int32_t* __restrict__ path_of,
+                                         const int32_t* __restrict__ e1, const float* __restrict__ coef1, const int32_t* __restrict__ e2,
+                                         const float* __restrict__ coef2, const float* __restrict__ const2, int64_t B, int spp,
+                                         float* __restrict__ L) {
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        for (int s = 0; s < spp; ++s) {
+            const int64_t i = b * spp + s;
+            f3 l = mk3(0.f, 0.f, 0.f);
+            if (e0[i] >= 0) l = ld3(radiance + (int64_t)e0[i] * 3);
+            const int j = path_of[i];
+            if (j >= 0) {
+                if (e1[j] >= 0) { f3 r = ld3(radiance + (int64_t)e1[j] * 3), c = ld3(coef1 + (int64_t)j * 3); l.x += c.x * r.x; l.y += c.y * r.y; l.z += c.z * r.z; }
+                f3 t2 = ld3(const2 + (int64_t)j * 3);
+                if (e2[j] >= 0) { f3 r = ld3(radiance + (int64_t)e2[j] * 3), c = ld3(coef2 + (int64_t)j * 3); t2.x += c.x * r.x; t2.y += c.y * r.y; t2.z += c.z * r.z; }
+                l.x += t2.x; l.y += t2.y; l.z += t2.z;
+            }
+            ax += l.x; ay += l.y; az += l.z;
+        }
+        const float inv = 1.0f / (float)spp;
+        st3(L + b * 3, mk3(ax * inv, ay * inv, az * inv));
+    }
+}
+// d radiance[e] += gL[b]/spp * coef   (scatter-add; few thousand rows, contention is irrelevant at 2.6e5 paths)
+__global__ void pt_accumulate_bwd_kernel(const float* __restrict__ gL, const int32_t* __restrict__ e0, const int32_t* __restrict__ path_of,
+                                         const int32_t* __restrict__ e1, const float* __restrict__ coef1, const int32_t* __restrict__ e2,
+                                         const float* __restrict__ coef2, int64_t B, int spp, float* __restrict__ g_radiance) {
+    const int64_t n = B * spp;
+    const float inv = 1.0f / (float)spp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / spp;
+        const f3 g = mk3(gL[b * 3] * inv, gL[b * 3 + 1] * inv, gL[b * 3 + 2] * inv);
+        if (e0[i] >= 0) { float* q = g_radiance + (int64_t)e0[i] * 3; atomicAdd(q, g.x); atomicAdd(q + 1, g.y); atomicAdd(q + 2, g.z); }
+        const int j = path_of[i];
+        if (j >= 0) {
+            if (e1[j] >= 0) { float* q = g_radiance + (int64_t)e1[j] * 3; f3 c = ld3(coef1 + (int64_t)j * 3); atomicAdd(q, g.x * c.x); atomicAdd(q + 1, g.y * c.y); atomicAdd(q + 2, g.z * c.z); }
+            if (e2[j] >= 0) { float* q = g_radiance + (int64_t)e2[j] * 3; f3 c = ld3(coef2 + (int64_t)j * 3); atomicAdd(q, g.x * c.x); atomicAdd(q + 1, g.y * c.y); atomicAdd(q + 2, g.z * c.z); }
+        }
+    }
+}
+
+// unfused call-surface kernels
+__global__ void sample_emitter_kernel(EmitSampleDev e, const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ pos,
+                                      int64_t N, float* __restrict__ wi, float* __restrict__ pdf, int64_t* __restrict__ tri) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        f3 w; float p; int64_t t;
+        sample_emitter1(e, s1[i], s2[i * 2], s2[i * 2 + 1], ld3(pos + i * 3), w, p, t);
+        st3(wi + i * 3, w); pdf[i] = p; tri[i] = t;
+    }
+}
+__global__ void eval_brdf_kernel(const float* __restrict__ wi, const float* __restrict__ wo, const float* __restrict__ nrm, const float* __restrict__ albedo,
+                                 const float* __restrict__ rough, const float* __restrict__ metal, int64_t N, float* __restrict__ brdf,
+                                 float* __restrict__ pdf) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        Mat m; m.albedo = ld3(albedo + i * 3); m.rough = rough[i]; m.metal = metal[i];
+        f3 b; float p;
+        eval_brdf1(ld3(wi + i * 3), ld3(wo + i * 3), ld3(nrm + i * 3), m, b, p);
+        st3(brdf + i * 3, b); pdf[i] = p;
+    }
+}
+__global__ void sample_brdf_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ wo, const float* __restrict__ nrm,
+                                   const float* __restrict__ albedo, const float* __restrict__ rough, const float* __restrict__ metal, int64_t N,
+                                   float* __restrict__ wi, float* __restrict__ pdf, float* __restrict__ weight) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        Mat m; m.albedo = ld3(albedo + i * 3); m.rough = rough[i]; m.metal = metal[i];
+        f3 w, bw; float p;
+        sample_brdf1(s1[i], s2[i * 2], s2[i * 2 + 1], ld3(wo + i * 3), ld3(nrm + i * 3), m, w, p, bw);
+        st3(wi + i * 3, w); pdf[i] = p; st3(weight + i * 3, bw);
+    }
+}
+
+}  // namespace iris

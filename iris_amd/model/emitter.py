@@ -47,9 +47,14 @@ class SLFEmitter(nn.Module):
             ie = np.ascontiguousarray(self.is_emitter.detach().cpu().numpy(), dtype=np.uint8)
             rad = L.host_f32(self.radiance).reshape(-1, 3)
             area = L.host_f32(self.emitter_area).reshape(-1)
+            verts = L.host_f32(self.emitter_vertices).reshape(-1)
+            cdf = L.host_f32(self.emitter_cdf).reshape(-1)
+            has_v = verts.size == area.shape[0] * 9 and area.shape[0] > 0
             h = C.c_void_p()
             L.check(L.lib().iris_emitter_create(ie.ctypes.data_as(C.c_void_p), ie.shape[0], rad.ctypes.data_as(C.c_void_p), rad.shape[0],
-                                                area.ctypes.data_as(C.c_void_p), area.shape[0], device.index or 0, C.byref(h)))
+                                                area.ctypes.data_as(C.c_void_p), area.shape[0],
+                                                verts.ctypes.data_as(C.c_void_p) if has_v else None, cdf.ctypes.data_as(C.c_void_p) if has_v else None,
+                                                device.index or 0, C.byref(h)))
             self._h, self._h_device = h, device
         return self._h
 
@@ -58,6 +63,15 @@ class SLFEmitter(nn.Module):
             self.refresh()
         except Exception:
             pass
+
+    def _sync_radiance(self, device):
+        """SLFEmitterLearn: the device-side radiance table follows the parameter (model/emitter.py:268)."""
+        r = self.radiance
+        ver = (r._version, r.data_ptr())
+        if isinstance(r, nn.Parameter) and getattr(self, "_rad_version", None) != ver and self._h is not None:
+            rr = r.detach().to(device=device, dtype=torch.float32).contiguous()
+            L.check(L.lib().iris_emitter_set_radiance(self._h, L.ptr(rr), rr.shape[0], L.stream()))
+            self._rad_version = ver
 
     def forward(self, position):
         """surface light field from queried location (model/emitter.py:175-178)"""
@@ -76,6 +90,36 @@ class SLFEmitter(nn.Module):
         pdf = torch.empty(B, 1, device=position.device, dtype=torch.float32)
         vn = torch.empty(B, device=position.device, dtype=torch.bool)
         with torch.cuda.device(position.device):
+            self.handle(position.device); self._sync_radiance(position.device)
             L.check(L.lib().iris_eval_emitter(self.handle(position.device), self.slf.handle(position.device), L.ptr(position),
                                               L.ptr(triangle_idx), L.ptr(r), float(trace_roughness), B, L.ptr(Le), L.ptr(pdf), L.ptr(vn), L.stream()))
         return Le, pdf, vn
+
+    def sample_emitter(self, sample1, sample2, position):
+        """importance sampling emitters (model/emitter.py:224-255): uniform emitter pick through the cdf, uniform point on
+        the triangle.  Returns wi Bx3, pdf Bx1 (area measure), triangle_idx B."""
+        sample1 = L.require_gpu(sample1, torch.float32, "sample1").reshape(-1)
+        sample2 = L.require_gpu(sample2, torch.float32, "sample2").reshape(-1, 2)
+        position = L.require_gpu(position, torch.float32, "position").reshape(-1, 3)
+        B = position.shape[0]
+        wi = torch.empty(B, 3, device=position.device, dtype=torch.float32)
+        pdf = torch.empty(B, 1, device=position.device, dtype=torch.float32)
+        tri = torch.empty(B, device=position.device, dtype=torch.int64)
+        with torch.cuda.device(position.device):
+            L.check(L.lib().iris_sample_emitter(self.handle(position.device), L.ptr(sample1), L.ptr(sample2), L.ptr(position), B, L.ptr(wi), L.ptr(pdf),
+                                                L.ptr(tri), L.stream()))
+        return wi, pdf, tri
+
+
+class SLFEmitterLearn(SLFEmitter):
+    """triangle emitters with a learnable radiance table (model/emitter.py:257-275)"""
+
+    def __init__(self, emitter_path, slf_path):
+        super().__init__(emitter_path, slf_path)
+        rad = self.radiance
+        del self._buffers["radiance"]
+        self.radiance = nn.Parameter(torch.FloatTensor(rad))
+
+    def update_slf(self, slf_path):
+        state_dict = torch.load(slf_path, map_location="cpu")
+        self.slf.load_state_dict(state_dict["weight"])

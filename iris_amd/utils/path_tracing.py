@@ -156,3 +156,97 @@ def ray_intersect(scene, xs, ds):
     with torch.cuda.device(xs.device):
         L.check(L.lib().iris_intersect(scene.handle, L.ptr(xs), L.ptr(ds), B, L.ptr(pos), L.ptr(nrm), L.ptr(uv), L.ptr(idx), L.ptr(valid), L.stream()))
     return pos, nrm, uv, idx, valid
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cfg 5: the one-bounce MIS path tracer the reference trains through (utils/path_tracing.py:320-407)
+# ----------------------------------------------------------------------------------------------------------------------
+class _PtAccumulate(torch.autograd.Function):
+    """L = mean_spp(radiance[e0] + coef1*radiance[e1] + coef2*radiance[e2] + const2): gather forward, scatter-add backward.
+    Only emitter.radiance receives gradient; geometry and sampled directions carry none."""
+
+    @staticmethod
+    def forward(ctx, radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp):
+        rad = radiance.detach().to(torch.float32).contiguous()
+        Lout = torch.empty(B, 3, device=rad.device, dtype=torch.float32)
+        with torch.cuda.device(rad.device):
+            L.check(L.lib().iris_pt_accumulate_fwd(L.ptr(rad), L.ptr(e0), L.ptr(path_of), L.ptr(e1), L.ptr(coef1), L.ptr(e2), L.ptr(coef2), L.ptr(const2),
+                                                   B, spp, L.ptr(Lout), L.stream()))
+        ctx.save_for_backward(e0, path_of, e1, coef1, e2, coef2)
+        ctx.meta = (B, spp, tuple(radiance.shape))
+        return Lout
+
+    @staticmethod
+    def backward(ctx, gL):
+        e0, path_of, e1, coef1, e2, coef2 = ctx.saved_tensors
+        B, spp, shape = ctx.meta
+        g = torch.zeros(shape, device=gL.device, dtype=torch.float32)
+        gL = gL.contiguous().to(torch.float32)
+        with torch.cuda.device(gL.device):
+            L.check(L.lib().iris_pt_accumulate_bwd(L.ptr(gL), L.ptr(e0), L.ptr(path_of), L.ptr(e1), L.ptr(coef1), L.ptr(e2), L.ptr(coef2), B, spp,
+                                                   L.ptr(g), L.stream()))
+        return (g,) + (None,) * 9
+
+
+def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, uniforms=None):
+    """Path trace the scene with one bounce and power-2 MIS (utils/path_tracing.py:320-407).
+
+    Args as the reference: rays_o, rays_d, dx_du, dy_dv Bx3; spp samples per pixel.  material_net(position) returns
+    {'albedo','roughness','metallic'} (the reference's NGPBRDF; any callable works).  uniforms: optional list of the five
+    draws the reference makes, [rand(2,B,spp,1), rand(N), rand(N,2), rand(N), rand(N,2)] (parity mode).
+    Returns L Bx3, differentiable with respect to emitter_net.radiance.
+    """
+    rays_o = L.require_gpu(rays_o, torch.float32, "rays_o").reshape(-1, 3)
+    rays_d = L.require_gpu(rays_d, torch.float32, "rays_d").reshape(-1, 3)
+    dx_du = L.require_gpu(dx_du, torch.float32, "dx_du").reshape(-1, 3)
+    dy_dv = L.require_gpu(dy_dv, torch.float32, "dy_dv").reshape(-1, 3)
+    B, dev = rays_o.shape[0], rays_o.device
+    lib = L.lib()
+    u = list(uniforms) if uniforms is not None else None
+    nxt = (lambda *shape: L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(*shape)) if u is not None else (lambda *shape: torch.rand(*shape, device=dev))
+
+    with torch.cuda.device(dev):
+        dudv = nxt(2, B, spp)
+        wi = torch.empty(B * spp, 3, device=dev)
+        L.check(lib.iris_pt_jitter(L.ptr(rays_d), L.ptr(dx_du), L.ptr(dy_dv), L.ptr(dudv), B, spp, L.ptr(wi), L.stream()))
+        position, normal, _, triangle_idx, _ = ray_intersect(scene, rays_o.repeat_interleave(spp, 0), wi)
+        e0 = torch.empty(B * spp, device=dev, dtype=torch.int32)
+        valid_next = torch.empty(B * spp, device=dev, dtype=torch.bool)
+        eh, sh = emitter_net.handle(dev), emitter_net.slf.handle(dev)
+        L.check(lib.iris_pt_primary_emit(eh, L.ptr(triangle_idx), B * spp, L.ptr(e0), L.ptr(valid_next), L.stream()))
+        radiance = emitter_net.radiance
+
+        if not bool(valid_next.any()):          # the reference returns the un-reduced (B*spp,3) tensor here (:347-348)
+            ext = torch.cat([radiance, radiance.new_zeros(1, 3)])
+            return ext[torch.where(e0 >= 0, e0.long(), torch.full_like(e0, radiance.shape[0]).long())]
+
+        sel = torch.nonzero(valid_next, as_tuple=False).reshape(-1)
+        N = sel.numel()
+        path_of = torch.full((B * spp,), -1, device=dev, dtype=torch.int32)
+        path_of[sel] = torch.arange(N, device=dev, dtype=torch.int32)
+        position, normal, wo = position[sel].contiguous(), normal[sel].contiguous(), (-wi[sel]).contiguous()
+
+        mat = material_net(position)
+        albedo = mat["albedo"].detach().to(torch.float32).reshape(-1, 3).contiguous()
+        rough = mat["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
+        metal = mat["metallic"].detach().to(torch.float32).reshape(-1).contiguous()
+
+        # direct illumination: emitter sampling + MIS (:357-382)
+        s1, s2 = nxt(N), nxt(N, 2)
+        coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
+        L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
+                                L.ptr(coef1), L.ptr(e1), L.stream()))
+        # BRDF sampling + next intersection (:384-391)
+        s1b, s2b = nxt(N), nxt(N, 2)
+        wi_b = torch.empty(N, 3, device=dev); pdf_b = torch.empty(N, device=dev); w_b = torch.empty(N, 3, device=dev)
+        pos_n = torch.empty(N, 3, device=dev); nrm_n = torch.empty(N, 3, device=dev)
+        tri_n = torch.empty(N, device=dev, dtype=torch.int64); hit_n = torch.empty(N, device=dev, dtype=torch.bool)
+        L.check(lib.iris_pt_brdf_trace(scene.handle, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1b), L.ptr(s2b), N,
+                                       L.ptr(wi_b), L.ptr(pdf_b), L.ptr(w_b), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(tri_n), L.ptr(hit_n), L.stream()))
+        mat_next = material_net(pos_n)
+        rough_n = mat_next["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
+        # eval_emitter at the sampled hit + MIS (:394-404)
+        coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
+        L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi_b), L.ptr(tri_n), L.ptr(rough_n), L.ptr(pdf_b), L.ptr(w_b), N,
+                                        L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.stream()))
+    return _PtAccumulate.apply(radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp)

@@ -364,6 +364,9 @@ typedef struct {
     const float *radiance;     /* rows indexed by emitter ordinal (model/emitter.py:203) */
     const float *area;         /* k */
     float emitter_pdf;         /* NF.normalize(ones(k),p=1) = 1/k (model/emitter.py:169) */
+    const float *verts;        /* (k,3,3) emitter_vertices, optional (sample_emitter) */
+    const float *cdf;          /* (k) emitter_cdf as torch computed it */
+    int64_t *ord2tri;          /* (k) triangle_idx buffer (model/emitter.py:165-166) */
 } orc_emitter;
 
 ORC_API orc_emitter *orc_emitter_create(const uint8_t *is_emitter, int64_t nf, const float *radiance, const float *area, int64_t k) {
@@ -374,9 +377,12 @@ ORC_API orc_emitter *orc_emitter_create(const uint8_t *is_emitter, int64_t nf, c
     for (int64_t i = 0; i < nf; ++i) e->emitter_idx[i] = is_emitter[i] ? c++ : -1;
     float s = (float)k; if (s < 1e-12f) s = 1e-12f;
     e->emitter_pdf = 1.0f / s;
+    e->ord2tri = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
+    for (int64_t i = 0; i < nf; ++i) if (e->emitter_idx[i] >= 0 && e->emitter_idx[i] < k) e->ord2tri[e->emitter_idx[i]] = i;
     return e;
 }
-ORC_API void orc_emitter_destroy(orc_emitter *e) { if (e) { free(e->emitter_idx); free(e); } }
+ORC_API void orc_emitter_set_sampling(orc_emitter *e, const float *verts, const float *cdf) { e->verts = verts; e->cdf = cdf; }
+ORC_API void orc_emitter_destroy(orc_emitter *e) { if (e) { free(e->emitter_idx); free(e->ord2tri); free(e); } }
 
 /* model/emitter.py:180-221 eval_emitter for one sample.  rough<0 encodes roughness=None. */
 static inline v3 eval_emitter1(const orc_emitter *e, const orc_slf *s, v3 p, int64_t tri, int has_rough, float rough,
@@ -784,4 +790,192 @@ ORC_API void orc_set_num_threads(int n) {
 #else
     (void)n;
 #endif
+}
+
+/* ============================================================================================
+ * a9 (cfg 5)  path_tracing_single  (utils/path_tracing.py:320-407) and its building blocks
+ * ========================================================================================== */
+typedef struct { v3 albedo; float rough, metal; } orc_mat;
+
+/* model/brdf.py:138-175 eval_brdf */
+static inline void eval_brdf1(v3 wi, v3 wo, v3 n, orc_mat m, v3 *brdf, float *pdf) {
+    v3 h = t_normalize(v3_make(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z));
+    float NoL = relu(t_dot(wi, n)), NoV = relu(t_dot(wo, n));
+    float VoH = relu(t_dot(wo, h)), NoH = relu(t_dot(n, h));
+    float D = D_GGX(NoH, m.rough);
+    float vc = VoH < 1e-4f ? 1e-4f : VoH;
+    float pdf_spec = D / (4.f * vc) * NoH;
+    float pdf_diff = NoL / PI_F;
+    *pdf = 0.5f * pdf_spec + 0.5f * pdf_diff;
+    float om = 1.f - m.metal;
+    v3 kd = v3_make(m.albedo.x * om, m.albedo.y * om, m.albedo.z * om);
+    v3 ks = v3_make(0.04f * om + m.albedo.x * m.metal, 0.04f * om + m.albedo.y * m.metal, 0.04f * om + m.albedo.z * m.metal);
+    float G = G1_GGX_Schlick(NoL, m.rough) * G1_GGX_Schlick(NoV, m.rough);
+    float x = pow5(1.f - VoH);
+    float dg = D * G;
+    brdf->x = kd.x / PI_F * NoL + dg * (ks.x + (1.f - ks.x) * x) / 4.0f * NoL;
+    brdf->y = kd.y / PI_F * NoL + dg * (ks.y + (1.f - ks.y) * x) / 4.0f * NoL;
+    brdf->z = kd.z / PI_F * NoL + dg * (ks.z + (1.f - ks.z) * x) / 4.0f * NoL;
+}
+/* model/brdf.py:177-210 sample_brdf */
+static inline void sample_brdf1(float s1, float u0, float u1, v3 wo, v3 n, orc_mat m, v3 *wi, float *pdf, v3 *w) {
+    *wi = (s1 > 0.5f) ? diffuse_sampler(u0, u1, n) : specular_sampler(u0, u1, m.rough, wo, n);
+    v3 brdf;
+    eval_brdf1(*wi, wo, n, m, &brdf, pdf);
+    *w = v3_make(0.f, 0.f, 0.f);
+    if (*pdf > 0.f) {
+        *w = v3_make(brdf.x / *pdf, brdf.y / *pdf, brdf.z / *pdf);
+        if (w->x != w->x) w->x = 0.f;
+        if (w->y != w->y) w->y = 0.f;
+        if (w->z != w->z) w->z = 0.f;
+    }
+}
+/* model/emitter.py:224-255 sample_emitter */
+static inline void sample_emitter1(const orc_emitter *e, float s1, float u0, float u1, v3 pos, v3 *wi, float *pdf, int64_t *tri) {
+    const float v = s1 < 1e-12f ? 1e-12f : s1;
+    int64_t lo = 0, hi = e->k;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (e->cdf[mid] < v) lo = mid + 1; else hi = mid; }
+    const int64_t ei = lo < e->k ? lo : e->k - 1;
+    const float xi1 = sqrtf(u0);
+    const float u = 1.f - xi1, vv = xi1 * u1, w = (1.f - u) - vv;
+    const float *p = e->verts + ei * 9;
+    v3 p1 = v3_make((p[0] * u + p[3] * vv) + p[6] * w, (p[1] * u + p[4] * vv) + p[7] * w, (p[2] * u + p[5] * vv) + p[8] * w);
+    *wi = t_normalize(v3_sub(p1, pos));
+    float a = e->area[ei]; if (a < 1e-12f) a = 1e-12f;
+    *pdf = e->emitter_pdf / a;
+    *tri = e->ord2tri[ei];
+}
+static inline orc_mat mat_at(const float *albedo, const float *rough, const float *metal, int64_t i) {
+    orc_mat m; m.albedo = v3_ld(albedo + i * 3); m.rough = rough[i]; m.metal = metal[i];
+    return m;
+}
+ORC_API void orc_sample_emitter(const orc_emitter *e, const float *s1, const float *s2, const float *pos, int64_t N, float *wi, float *pdf, int64_t *tri) {
+    for (int64_t i = 0; i < N; ++i) { v3 w; sample_emitter1(e, s1[i], s2[i * 2], s2[i * 2 + 1], v3_ld(pos + i * 3), &w, pdf + i, tri + i); v3_st(wi + i * 3, w); }
+}
+ORC_API void orc_eval_brdf(const float *wi, const float *wo, const float *nrm, const float *albedo, const float *rough, const float *metal, int64_t N,
+                           float *brdf, float *pdf) {
+    for (int64_t i = 0; i < N; ++i) { v3 b; eval_brdf1(v3_ld(wi + i * 3), v3_ld(wo + i * 3), v3_ld(nrm + i * 3), mat_at(albedo, rough, metal, i), &b, pdf + i); v3_st(brdf + i * 3, b); }
+}
+ORC_API void orc_sample_brdf(const float *s1, const float *s2, const float *wo, const float *nrm, const float *albedo, const float *rough, const float *metal,
+                             int64_t N, float *wi, float *pdf, float *weight) {
+    for (int64_t i = 0; i < N; ++i) {
+        v3 w, bw;
+        sample_brdf1(s1[i], s2[i * 2], s2[i * 2 + 1], v3_ld(wo + i * 3), v3_ld(nrm + i * 3), mat_at(albedo, rough, metal, i), &w, pdf + i, &bw);
+        v3_st(wi + i * 3, w); v3_st(weight + i * 3, bw);
+    }
+}
+/* utils/path_tracing.py:338-340 */
+ORC_API void orc_pt_jitter(const float *rays_d, const float *dxdu, const float *dydv, const float *dudv, int64_t B, int spp, float *wi) {
+    const int64_t n = B * spp;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t b = i / spp;
+        const float du = dudv[i] - 0.5f, dv = dudv[n + i] - 0.5f;
+        v3 d = v3_ld(rays_d + b * 3), dx = v3_ld(dxdu + b * 3), dy = v3_ld(dydv + b * 3);
+        v3_st(wi + i * 3, t_normalize(v3_make((d.x + dx.x * du) + dy.x * dv, (d.y + dx.y * du) + dy.y * dv, (d.z + dx.z * du) + dy.z * dv)));
+    }
+}
+static inline v3 ff_normal(const orc_scene *sc, const orc_hit *h, v3 d) {
+    v3 n = t_normalize(hit_normal(sc, h));
+    if (t_dot(n, v3_make(-d.x, -d.y, -d.z)) < 0.f) n = v3_make(-n.x, -n.y, -n.z);
+    return n;
+}
+/* :357-382  term1 = coef1 * radiance[e1] */
+ORC_API void orc_pt_nee(const orc_scene *sc, const orc_emitter *e, const float *pos, const float *nrm, const float *wo, const float *albedo,
+                        const float *rough, const float *metal, const float *s1, const float *s2, int64_t N, float *coef1, int32_t *e1) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; ++i) {
+        const v3 x = v3_ld(pos + i * 3), n = v3_ld(nrm + i * 3), w = v3_ld(wo + i * 3);
+        v3 wi; float emit_pdf; int64_t emit_tri;
+        sample_emitter1(e, s1[i], s2[i * 2], s2[i * 2 + 1], x, &wi, &emit_pdf, &emit_tri);
+        const v3 o = v3_make(x.x + RAY_EPS * wi.x, x.y + RAY_EPS * wi.y, x.z + RAY_EPS * wi.z);
+        orc_hit h = intersect_bvh(sc, o, wi, NULL, NULL);
+        const int emit_valid = h.tri >= 0;
+        int64_t ord = -1; float G = 1.f; int emit_vis = 1;
+        if (emit_valid) {
+            const v3 ep = hit_position(sc, &h), en = ff_normal(sc, &h, wi);
+            emit_vis = emit_tri == h.tri;
+            ord = e->is_emitter[h.tri] ? e->emitter_idx[h.tri] : -1;
+            const v3 dl = v3_sub(ep, x);
+            float d2 = (dl.x * dl.x + dl.y * dl.y) + dl.z * dl.z; if (d2 < 1e-6f) d2 = 1e-6f;
+            G = fabsf(t_dot(v3_make(-wi.x, -wi.y, -wi.z), en)) / d2;
+        }
+        v3 brdf; float brdf_pdf;
+        eval_brdf1(wi, w, n, mat_at(albedo, rough, metal, i), &brdf, &brdf_pdf);
+        brdf_pdf = brdf_pdf * G;
+        float w_mis = 0.f;
+        if (emit_pdf > 0.f && !isinf(brdf_pdf)) { float den = emit_pdf * emit_pdf + brdf_pdf * brdf_pdf; if (den < 1e-6f) den = 1e-6f; w_mis = emit_pdf * emit_pdf / den; }
+        if (isinf(emit_pdf) || brdf_pdf == 0.f) w_mis = 1.f;
+        const float sv = emit_vis ? 1.f : 0.f;
+        const float ew = G / (emit_pdf < 1e-6f ? 1e-6f : emit_pdf);
+        v3_st(coef1 + i * 3, v3_make(brdf.x * (sv * ew) * w_mis, brdf.y * (sv * ew) * w_mis, brdf.z * (sv * ew) * w_mis));
+        e1[i] = (emit_valid && ord >= 0) ? (int32_t)ord : -1;
+    }
+}
+/* :384-391 */
+ORC_API void orc_pt_brdf_trace(const orc_scene *sc, const float *pos, const float *nrm, const float *wo, const float *albedo, const float *rough,
+                               const float *metal, const float *s1, const float *s2, int64_t N, float *wi_out, float *pdf_out, float *w_out,
+                               float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; ++i) {
+        const v3 x = v3_ld(pos + i * 3), n = v3_ld(nrm + i * 3), w = v3_ld(wo + i * 3);
+        v3 wi, bw; float pdf;
+        sample_brdf1(s1[i], s2[i * 2], s2[i * 2 + 1], w, n, mat_at(albedo, rough, metal, i), &wi, &pdf, &bw);
+        const v3 o = v3_make(x.x + RAY_EPS * wi.x, x.y + RAY_EPS * wi.y, x.z + RAY_EPS * wi.z);
+        orc_hit h = intersect_bvh(sc, o, wi, NULL, NULL);
+        v3 pn = v3_make(0, 0, 0), nn = v3_make(0, 0, 0);
+        if (h.tri >= 0) { pn = hit_position(sc, &h); nn = ff_normal(sc, &h, wi); }
+        v3_st(wi_out + i * 3, wi); pdf_out[i] = pdf; v3_st(w_out + i * 3, bw);
+        v3_st(pos_next + i * 3, pn); v3_st(nrm_next + i * 3, nn); tri_next[i] = h.tri; valid[i] = h.tri >= 0;
+    }
+}
+/* :394-404  term2 = coef2 * radiance[e2] + const2 */
+ORC_API void orc_pt_brdf_finish(const orc_emitter *e, const orc_slf *slf, const float *pos, const float *pos_next, const float *nrm_next, const float *wi_in,
+                                const int64_t *tri_next, const float *rough_next, const float *pdf_in, const float *w_in, int64_t N, float *coef2,
+                                float *const2, int32_t *e2) {
+    for (int64_t i = 0; i < N; ++i) {
+        const v3 x = v3_ld(pos + i * 3), pn = v3_ld(pos_next + i * 3), nn = v3_ld(nrm_next + i * 3), wi = v3_ld(wi_in + i * 3);
+        const int64_t tri = tri_next[i];
+        const int vis = tri != -1;
+        const int is_area = vis && e->is_emitter[tri];
+        int64_t ord = is_area ? e->emitter_idx[tri] : -1;
+        float emit_pdf = 0.f;
+        if (is_area) { float a = e->area[ord]; if (a < 1e-12f) a = 1e-12f; emit_pdf = e->emitter_pdf / a; }
+        int valid_next = (!is_area) && vis;
+        v3 sl = v3_make(0, 0, 0);
+        if ((!is_area) && vis && rough_next[i] > 0.0f) { sl = slf_forward(slf, pn); if ((sl.x + sl.y) + sl.z > 0.f) valid_next = 0; }
+        const v3 dl = v3_sub(x, pn);
+        float d2 = (dl.x * dl.x + dl.y * dl.y) + dl.z * dl.z; if (d2 < 1e-6f) d2 = 1e-6f;
+        float G = fabsf(t_dot(v3_make(-nn.x, -nn.y, -nn.z), wi)) / d2;
+        if (!valid_next) G = 1.f;
+        const float brdf_pdf = pdf_in[i] * G;
+        float w_mis = 0.f;
+        if (brdf_pdf > 0.f && !isinf(emit_pdf)) w_mis = brdf_pdf * brdf_pdf / (emit_pdf * emit_pdf + brdf_pdf * brdf_pdf);
+        if (isinf(brdf_pdf) || emit_pdf == 0.f) w_mis = 1.f;
+        const v3 w = v3_ld(w_in + i * 3);
+        v3_st(coef2 + i * 3, v3_make(w.x * w_mis, w.y * w_mis, w.z * w_mis));
+        v3_st(const2 + i * 3, v3_make(w.x * sl.x * w_mis, w.y * sl.y * w_mis, w.z * sl.z * w_mis));
+        e2[i] = is_area ? (int32_t)ord : -1;
+    }
+}
+/* :344, :382, :404, :406  (same summation order as the HIP accumulate kernel) */
+ORC_API void orc_pt_accumulate(const float *radiance, const int32_t *e0, const int32_t *path_of, const int32_t *e1, const float *coef1, const int32_t *e2,
+                               const float *coef2, const float *const2, int64_t B, int spp, float *L) {
+    for (int64_t b = 0; b < B; ++b) {
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        for (int s = 0; s < spp; ++s) {
+            const int64_t i = b * spp + s;
+            v3 l = v3_make(0, 0, 0);
+            if (e0[i] >= 0) l = v3_ld(radiance + (int64_t)e0[i] * 3);
+            const int j = path_of[i];
+            if (j >= 0) {
+                if (e1[j] >= 0) { v3 r = v3_ld(radiance + (int64_t)e1[j] * 3), c = v3_ld(coef1 + (int64_t)j * 3); l.x += c.x * r.x; l.y += c.y * r.y; l.z += c.z * r.z; }
+                v3 t2 = v3_ld(const2 + (int64_t)j * 3);
+                if (e2[j] >= 0) { v3 r = v3_ld(radiance + (int64_t)e2[j] * 3), c = v3_ld(coef2 + (int64_t)j * 3); t2.x += c.x * r.x; t2.y += c.y * r.y; t2.z += c.z * r.z; }
+                l.x += t2.x; l.y += t2.y; l.z += t2.z;
+            }
+            ax += l.x; ay += l.y; az += l.z;
+        }
+        const float inv = 1.0f / (float)spp;
+        v3_st(L + b * 3, v3_make(ax * inv, ay * inv, az * inv));
+    }
 }

@@ -155,13 +155,23 @@ class VoxelSLF:
 
 
 class SLFEmitter:
-    def __init__(self, is_emitter, emitter_radiance, emitter_area, slf):
+    def __init__(self, is_emitter, emitter_radiance, emitter_area, slf, emitter_vertices=None, emitter_cdf=None):
         self.is_emitter = np.ascontiguousarray(is_emitter, dtype=np.uint8)
         self.radiance = _f32(emitter_radiance).reshape(-1, 3)
         self.area = _f32(emitter_area).reshape(-1)
         self.slf = slf
         self.h = C.c_void_p(lib().orc_emitter_create(_p(self.is_emitter), C.c_int64(self.is_emitter.shape[0]), _p(self.radiance),
                                                      _p(self.area), C.c_int64(self.area.shape[0])))
+        if emitter_vertices is not None:
+            self.verts = _f32(emitter_vertices).reshape(-1)
+            self.cdf = _f32(emitter_cdf).reshape(-1)
+            lib().orc_emitter_set_sampling(self.h, _p(self.verts), _p(self.cdf))
+
+    def sample_emitter(self, s1, s2, position):
+        s1 = _f32(s1).reshape(-1); s2 = _f32(s2).reshape(-1, 2); position = _f32(position); N = position.shape[0]
+        wi = np.empty((N, 3), np.float32); pdf = np.empty((N, 1), np.float32); tri = np.empty(N, np.int64)
+        lib().orc_sample_emitter(self.h, _p(s1), _p(s2), _p(position), C.c_int64(N), _p(wi), _p(pdf), _p(tri))
+        return wi, pdf, tri
 
     def eval_emitter(self, position, triangle_idx, roughness=None, trace_roughness=0.6):
         position = _f32(position); tri = np.ascontiguousarray(triangle_idx, dtype=np.int64); B = position.shape[0]
@@ -228,3 +238,73 @@ def bake(scene, emitter, position, normal, spp, wo=None, roughness=None, u2=None
     if counters:
         res = res + (cnt,)
     return res
+
+
+# ---------------------------------------------------------------- a9 (cfg 5)
+def _mat(mat):
+    return _f32(mat["albedo"]).reshape(-1, 3), _f32(mat["roughness"]).reshape(-1), _f32(mat["metallic"]).reshape(-1)
+
+
+def eval_brdf(wi, wo, normal, mat):
+    wi = _f32(wi); wo = _f32(wo); normal = _f32(normal); a, r, m = _mat(mat); N = wi.shape[0]
+    brdf = np.empty((N, 3), np.float32); pdf = np.empty((N, 1), np.float32)
+    lib().orc_eval_brdf(_p(wi), _p(wo), _p(normal), _p(a), _p(r), _p(m), C.c_int64(N), _p(brdf), _p(pdf))
+    return brdf, pdf
+
+
+def sample_brdf(s1, s2, wo, normal, mat):
+    s1 = _f32(s1).reshape(-1); s2 = _f32(s2).reshape(-1, 2); wo = _f32(wo); normal = _f32(normal); a, r, m = _mat(mat); N = wo.shape[0]
+    wi = np.empty((N, 3), np.float32); pdf = np.empty((N, 1), np.float32); w = np.empty((N, 3), np.float32)
+    lib().orc_sample_brdf(_p(s1), _p(s2), _p(wo), _p(normal), _p(a), _p(r), _p(m), C.c_int64(N), _p(wi), _p(pdf), _p(w))
+    return wi, pdf, w
+
+
+def path_tracing_single(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_dv, spp, uniforms, radiance=None):
+    """utils/path_tracing.py:320-407.  material_fn(position ndarray) -> dict of ndarrays.  uniforms: the five draws.
+    Returns (L (B,3), terms) where terms lets grad_radiance() form dL/d radiance analytically."""
+    rays_o = _f32(rays_o); rays_d = _f32(rays_d); dx_du = _f32(dx_du); dy_dv = _f32(dy_dv); B = rays_o.shape[0]
+    rad = emitter.radiance if radiance is None else _f32(radiance).reshape(-1, 3)
+    u = [np.ascontiguousarray(np.asarray(x, np.float32)) for x in uniforms]
+    dudv = u[0].reshape(2, B, spp)
+    wi = np.empty((B * spp, 3), np.float32)
+    lib().orc_pt_jitter(_p(rays_d), _p(dx_du), _p(dy_dv), _p(dudv), C.c_int64(B), C.c_int(spp), _p(wi))
+    pos, nrm, _, tri, vis = scene.ray_intersect(np.repeat(rays_o, spp, 0), wi)
+    is_area = emitter.is_emitter[np.where(tri < 0, 0, tri)].astype(bool) & (tri >= 0)
+    ord_of = np.cumsum(emitter.is_emitter.astype(np.int64)) - 1
+    e0 = np.where(is_area, ord_of[np.where(tri < 0, 0, tri)], -1).astype(np.int32)
+    valid_next = (~is_area) & (tri >= 0)
+    sel = np.nonzero(valid_next)[0]; N = len(sel)
+    path_of = np.full(B * spp, -1, np.int32); path_of[sel] = np.arange(N, dtype=np.int32)
+    pos, nrm, wo = _f32(pos[sel]), _f32(nrm[sel]), _f32(-wi[sel])
+    a, r, m = _mat(material_fn(pos))
+    s1, s2, s1b, s2b = u[1].reshape(-1), u[2].reshape(-1, 2), u[3].reshape(-1), u[4].reshape(-1, 2)
+    coef1 = np.empty((N, 3), np.float32); e1 = np.empty(N, np.int32)
+    lib().orc_pt_nee(scene.h, emitter.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(coef1), _p(e1))
+    wi_b = np.empty((N, 3), np.float32); pdf_b = np.empty(N, np.float32); w_b = np.empty((N, 3), np.float32)
+    pos_n = np.empty((N, 3), np.float32); nrm_n = np.empty((N, 3), np.float32); tri_n = np.empty(N, np.int64); hit_n = np.empty(N, np.uint8)
+    lib().orc_pt_brdf_trace(scene.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1b), _p(s2b), C.c_int64(N), _p(wi_b), _p(pdf_b), _p(w_b),
+                            _p(pos_n), _p(nrm_n), _p(tri_n), _p(hit_n))
+    _, r_n, _ = _mat(material_fn(pos_n))
+    coef2 = np.empty((N, 3), np.float32); const2 = np.empty((N, 3), np.float32); e2 = np.empty(N, np.int32)
+    lib().orc_pt_brdf_finish(emitter.h, emitter.slf.h, _p(pos), _p(pos_n), _p(nrm_n), _p(wi_b), _p(tri_n), _p(r_n), _p(pdf_b), _p(w_b), C.c_int64(N),
+                             _p(coef2), _p(const2), _p(e2))
+    Lout = np.empty((B, 3), np.float32)
+    lib().orc_pt_accumulate(_p(rad), _p(e0), _p(path_of), _p(e1), _p(coef1), _p(e2), _p(coef2), _p(const2), C.c_int64(B), C.c_int(spp), _p(Lout))
+    terms = {"e0": e0, "path_of": path_of, "e1": e1, "coef1": coef1, "e2": e2, "coef2": coef2, "const2": const2, "B": B, "spp": spp,
+             "tri_next": tri_n, "position": pos, "position_next": pos_n}
+    return Lout, terms
+
+
+def grad_radiance(terms, gL, n_rad):
+    """dL/d radiance (n_rad,3) for upstream gradient gL (B,3): scatter of gL/spp * coefficient (float64 accumulate)."""
+    B, spp = terms["B"], terms["spp"]
+    g = np.zeros((n_rad, 3), np.float64)
+    gp = np.repeat(np.asarray(gL, np.float64) / spp, spp, 0)
+    m = terms["e0"] >= 0
+    np.add.at(g, terms["e0"][m], gp[m])
+    act = terms["path_of"] >= 0
+    j = terms["path_of"][act]
+    for e, c in ((terms["e1"], terms["coef1"]), (terms["e2"], terms["coef2"])):
+        mm = e[j] >= 0
+        np.add.at(g, e[j][mm], gp[act][mm] * c[j][mm].astype(np.float64))
+    return g.astype(np.float32)

@@ -1,0 +1,130 @@
+"""BASELINE cfg 5 / SURVEY.md section 8 a9: path_tracing_single (utils/path_tracing.py:320-407) and its building blocks
+sample_emitter / eval_brdf / sample_brdf, forward and d/d(emitter.radiance).
+
+Goldens (tests/golden/pt_units.npz, pt_single.npz) come from the reference's own Python (tools/make_goldens.py) with a
+closed-form stub material (the NGP hash grid is third party) and the oracle's closest hit patched in for Mitsuba."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+from stub_material import StubMaterial, stub_material_np
+
+
+@pytest.fixture(params=[0, 1], ids=["libm", "device-arithmetic"])
+def omode(request, oracle_mod):
+    oracle_mod.set_mode(request.param)
+    yield request.param
+    oracle_mod.set_mode(0)
+
+
+def _box(oracle_mod, with_sampling=True):
+    g, p = golden("bake_box.npz"), golden("pt_single.npz")
+    sc = oracle_mod.Scene(g["verts"], g["faces"])
+    slf = oracle_mod.VoxelSLF(g["slf_inds"], g["slf_radiance"], float(g["voxel_min"]), float(g["voxel_max"]))
+    em = oracle_mod.SLFEmitter(g["is_emitter"], g["emitter_radiance"], g["emitter_area"], slf, p["emitter_vertices"], p["emitter_cdf"])
+    return g, p, sc, em
+
+
+def check_units(got_se, got_eb, got_sb, u):
+    wi, pdf, tri = got_se
+    np.testing.assert_array_equal(tri, u["se_tri"])
+    np.testing.assert_allclose(wi, u["se_wi"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(pdf, u["se_pdf"], rtol=1e-6)
+    brdf, bpdf = got_eb
+    assert rel_l2(brdf, u["brdf"]) <= 1e-5 and rel_l2(bpdf, u["brdf_pdf"]) <= 1e-5
+    np.testing.assert_allclose(brdf, u["brdf"], rtol=2e-4, atol=1e-5)
+    swi, spdf, sw = got_sb
+    np.testing.assert_allclose(swi, u["sb_wi"], atol=8e-6, rtol=0)
+    up = (u["wo"] * u["normal"]).sum(-1) > 0.02                      # the path only produces wo above the surface
+    assert rel_l2(sw[up], u["sb_weight"][up]) <= 1e-5                 # brdf/pdf: the GGX D cancels -> well conditioned
+    # the pdf itself carries D_GGX, whose denominator NoH^2(a^2-1)+1 cancels for peaked lobes (values up to 9e4 here)
+    ok = np.abs(spdf - u["sb_pdf"])[up] <= 1e-3 * np.abs(u["sb_pdf"][up]) + 1e-5
+    assert ok.mean() >= 0.98 and rel_l2(spdf[up], u["sb_pdf"][up]) <= 1e-2
+
+
+def test_oracle_units(oracle_mod, omode):
+    _, _, _, em = _box(oracle_mod)
+    u = golden("pt_units.npz")
+    mat = {"albedo": u["albedo"], "roughness": u["roughness"], "metallic": u["metallic"]}
+    check_units(em.sample_emitter(u["s1"], u["s2"], u["position"]), oracle_mod.eval_brdf(u["wi"], u["wo"], u["normal"], mat),
+                oracle_mod.sample_brdf(u["sb_s1"], u["sb_s2"], u["wo"], u["normal"], mat), u)
+
+
+def test_oracle_path_tracing_single(oracle_mod, omode):
+    g, p, sc, em = _box(oracle_mod)
+    L, terms = oracle_mod.path_tracing_single(sc, em, stub_material_np, p["rays_o"], p["rays_d"], p["dx_du"], p["dy_dv"], int(p["spp"]),
+                                              [p[f"u{k}"] for k in range(5)], radiance=p["radiance"])
+    assert len(terms["e1"]) == p["u1"].shape[0]                       # same number of surviving paths as the reference drew for
+    assert rel_l2(L, p["L"]) <= 1e-5
+    gr = oracle_mod.grad_radiance(terms, p["grad_weight"], p["radiance"].shape[0])
+    assert rel_l2(gr, p["grad_radiance"]) <= 1e-5
+    assert (np.abs(p["grad_radiance"]).sum(-1) > 0).sum() >= 1
+
+
+# --------------------------------------------------------------------------------------------------------- GPU
+def _gpu_setup(tmp_path, dev):
+    from iris_amd.model.emitter import SLFEmitterLearn
+    from iris_amd.model.slf import VoxelSLF
+    from iris_amd.utils.path_tracing import Scene
+    g, p = golden("bake_box.npz"), golden("pt_single.npz")
+    slf = VoxelSLF(torch.from_numpy(g["slf_mask"]), float(g["voxel_min"]), float(g["voxel_max"]))
+    slf.radiance[:] = torch.from_numpy(g["slf_radiance"])
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    torch.save({"is_emitter": torch.from_numpy(g["is_emitter"]), "emitter_vertices": torch.from_numpy(p["emitter_vertices"]),
+                "emitter_area": torch.from_numpy(g["emitter_area"]), "emitter_normal": torch.zeros(2, 3),
+                "emitter_radiance": torch.from_numpy(p["radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(g["slf_mask"]), "voxel_min": float(g["voxel_min"]), "voxel_max": float(g["voxel_max"]), "weight": slf.state_dict()}, sp)
+    em = SLFEmitterLearn(ep, sp).to(dev)
+    return g, p, Scene(g["verts"], g["faces"], device=dev), em
+
+
+@pytest.mark.gpu
+def test_hip_units(tmp_path, oracle_mod):
+    from iris_amd.model.brdf import BaseBRDF
+    dev = torch.device("cuda:0")
+    _, _, _, em = _gpu_setup(tmp_path, dev)
+    u = golden("pt_units.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    N = lambda t: t.detach().cpu().numpy()
+    mat = {"albedo": T(u["albedo"]), "roughness": T(u["roughness"]), "metallic": T(u["metallic"])}
+    np.testing.assert_array_equal(N(em.emitter_cdf), u["emitter_cdf"])      # torch reproduces the reference's cdf buffer
+    se = tuple(N(t) for t in em.sample_emitter(T(u["s1"]), T(u["s2"]), T(u["position"])))
+    eb = tuple(N(t) for t in BaseBRDF().eval_brdf(T(u["wi"]), T(u["wo"]), T(u["normal"]), mat))
+    sb = tuple(N(t) for t in BaseBRDF().sample_brdf(T(u["sb_s1"]), T(u["sb_s2"]), T(u["wo"]), T(u["normal"]), mat))
+    check_units(se, eb, sb, u)
+    # bit for bit against the device-arithmetic oracle
+    _, _, _, oem = _box(oracle_mod)
+    omat = {"albedo": u["albedo"], "roughness": u["roughness"], "metallic": u["metallic"]}
+    with oracle_mod.device_arithmetic():
+        ose = oem.sample_emitter(u["s1"], u["s2"], u["position"])
+        oeb = oracle_mod.eval_brdf(u["wi"], u["wo"], u["normal"], omat)
+        osb = oracle_mod.sample_brdf(u["sb_s1"], u["sb_s2"], u["wo"], u["normal"], omat)
+    for a, b in zip(se + eb + sb, ose + oeb + osb):
+        np.testing.assert_array_equal(a.reshape(b.shape), b)
+
+
+@pytest.mark.gpu
+def test_hip_path_tracing_single_forward_backward(tmp_path, oracle_mod):
+    from iris_amd.utils.path_tracing import path_tracing_single
+    dev = torch.device("cuda:0")
+    g, p, sc, em = _gpu_setup(tmp_path, dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    unif = [T(p[f"u{k}"]) for k in range(5)]
+    L = path_tracing_single(sc, em, StubMaterial(), T(p["rays_o"]), T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]), int(p["spp"]), uniforms=unif)
+    assert L.shape == (p["rays_o"].shape[0], 3) and L.requires_grad
+    assert rel_l2(L.detach().cpu().numpy(), p["L"]) <= 1e-5                  # vs the reference
+    (gr,) = torch.autograd.grad((L * T(p["grad_weight"])).sum(), em.radiance)
+    assert rel_l2(gr.cpu().numpy(), p["grad_radiance"]) <= 1e-5             # vs the reference's autograd
+    # forward bit for bit against the device-arithmetic oracle (same staging, same material inputs)
+    _, _, osc, oem = _box(oracle_mod)
+    with oracle_mod.device_arithmetic():
+        oL, terms = oracle_mod.path_tracing_single(osc, oem, stub_material_np, p["rays_o"], p["rays_d"], p["dx_du"], p["dy_dv"], int(p["spp"]),
+                                                   [p[f"u{k}"] for k in range(5)], radiance=p["radiance"])
+    np.testing.assert_array_equal(L.detach().cpu().numpy(), oL)
+    # random draws path (no uniforms given): finite, deterministic shape, gradient reaches only emitter rows
+    torch.manual_seed(0)
+    L2 = path_tracing_single(sc, em, StubMaterial(), T(p["rays_o"]), T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]), 8)
+    (g2,) = torch.autograd.grad(L2.sum(), em.radiance)
+    assert torch.isfinite(L2).all() and torch.isfinite(g2).all()
+    assert int((g2.abs().sum(-1) > 0).sum()) <= int(g["is_emitter"].sum())

@@ -304,6 +304,62 @@ def main():
         out[f"Ls0_{r_idx}"] = Ls0_.numpy(); out[f"Ls1_{r_idx}"] = Ls1_.numpy()
     np.savez_compressed(os.path.join(OUT, "bake_box.npz"), **out)
 
+    # ------------------------------------------------------------------ a9 (cfg 5): building blocks
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from stub_material import StubMaterial
+    from model.emitter import SLFEmitterLearn
+    torch.manual_seed(1)
+    bev_real = torch.from_numpy(verts[faces[12:]])                      # true emitter vertices of the box-room light
+    torch.save({"is_emitter": b_is_emitter, "emitter_vertices": bev_real, "emitter_area": barea,
+                "emitter_normal": torch.zeros(2, 3), "emitter_radiance": brad}, emitter_path)
+    em_l = SLFEmitterLearn(emitter_path, slf_path)
+    Nq = 2048
+    posq = torch.rand(Nq, 3) * torch.tensor([4.0, 3.0, 2.4]) + torch.tensor([0.0, 0.0, 0.05])
+    s1q, s2q = torch.rand(Nq), torch.rand(Nq, 2)
+    s1q[:4] = torch.tensor([0.0, 1e-13, 0.5, 0.99999994])
+    wi_e, pdf_e, tri_e = em_l.sample_emitter(s1q, s2q, posq)
+    nq = unit(rng.normal(size=(Nq, 3))); woq = unit(nq + 0.7 * rng.normal(size=(Nq, 3))); wiq = unit(nq + 0.7 * rng.normal(size=(Nq, 3)))
+    mat_q = StubMaterial()(posq)
+    brdf_q, bpdf_q = material_net.eval_brdf(torch.from_numpy(wiq), torch.from_numpy(woq), torch.from_numpy(nq), mat_q)
+    s1b, s2b = torch.rand(Nq), torch.rand(Nq, 2)
+    wi_s, pdf_s, w_s = material_net.sample_brdf(s1b, s2b, torch.from_numpy(woq), torch.from_numpy(nq), mat_q)
+    np.savez(os.path.join(OUT, "pt_units.npz"), position=posq.numpy(), s1=s1q.numpy(), s2=s2q.numpy(), emitter_vertices=bev_real.numpy(),
+             emitter_cdf=em_l.emitter_cdf.numpy(), se_wi=wi_e.numpy(), se_pdf=pdf_e.numpy(), se_tri=tri_e.numpy(),
+             normal=nq, wo=woq, wi=wiq, albedo=mat_q["albedo"].numpy(), roughness=mat_q["roughness"].numpy(), metallic=mat_q["metallic"].numpy(),
+             brdf=brdf_q.numpy(), brdf_pdf=bpdf_q.numpy(), sb_s1=s1b.numpy(), sb_s2=s2b.numpy(), sb_wi=wi_s.numpy(), sb_pdf=pdf_s.numpy(), sb_weight=w_s.numpy())
+
+    # ------------------------------------------------------------------ a9 (cfg 5): path_tracing_single forward + d/d radiance
+    Hp = Wp = 16
+    Kp = torch.tensor([[0.8 * Wp, 0, Wp / 2], [0, 0.8 * Wp, Hp / 2], [0, 0, 1]], dtype=torch.float32)
+    fwd2 = np.array([0.3, 0.2, 1.0]); fwd2 /= np.linalg.norm(fwd2)      # looking up at the ceiling light
+    right2 = np.cross(fwd2, [0, 1.0, 0]); right2 /= np.linalg.norm(right2)
+    down2 = np.cross(fwd2, right2)
+    c2wp = torch.tensor(np.concatenate([np.stack([right2, down2, fwd2], 1), np.array([[2.0], [1.5], [0.9]])], 1), dtype=torch.float32)
+    ro, rd, dxdu, dydv = real_ldr.to_world(real_ldr.get_direction(Kp, (Hp, Wp)), c2wp, True, Kp)
+    spp_p = 4
+    recorded = []
+    real_rand = torch.rand
+
+    def rec_rand(*a, **k):
+        k.pop("device", None)
+        t = real_rand(*a, **k); recorded.append(t.clone()); return t
+    torch.rand = rec_rand
+    try:
+        torch.manual_seed(2)
+        class RefStub(BaseBRDF):            # the reference's NGPBRDF is a BaseBRDF with a forward(position) (model/brdf.py:213-260)
+            def forward(self, x):
+                return StubMaterial()(x)
+        Lp = rpt.path_tracing_single(None, em_l, RefStub(), ro, rd, dxdu, dydv, spp_p)
+    finally:
+        torch.rand = real_rand
+    wgt = torch.rand(Lp.shape[0], 3)
+    (gr,) = torch.autograd.grad((Lp * wgt).sum(), em_l.radiance)
+    np.savez(os.path.join(OUT, "pt_single.npz"), rays_o=ro.numpy(), rays_d=rd.numpy(), dx_du=dxdu.numpy(), dy_dv=dydv.numpy(), spp=spp_p,
+             u0=recorded[0].numpy(), u1=recorded[1].numpy(), u2=recorded[2].numpy(), u3=recorded[3].numpy(), u4=recorded[4].numpy(),
+             L=Lp.detach().numpy(), grad_weight=wgt.numpy(), grad_radiance=gr.numpy(), emitter_vertices=bev_real.numpy(),
+             emitter_cdf=em_l.emitter_cdf.numpy(), radiance=em_l.radiance.detach().numpy())
+    print("pt_single: L mean", float(Lp.mean()), "grad nnz rows", int((gr.abs().sum(-1) > 0).sum()), "draws", [tuple(r.shape) for r in recorded])
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
