@@ -43,11 +43,11 @@ enum { IRIS_OK = 0, IRIS_ERR_ARG = 1, IRIS_ERR_HIP = 2, IRIS_ERR_BUILD = 3 };
 #define IRIS_RAY_EPSILON 8.940696716308594e-05f /* mitsuba.math.RayEpsilon (float32) = 1500 * 2^-24 */
 
 /* BVH layouts selectable at scene creation (kernel-choice experiments) */
-enum { IRIS_BVH_DEFAULT = 0, IRIS_BVH4_F32 = 1, IRIS_BVH8_Q8 = 2 };
+enum { IRIS_BVH_DEFAULT = 0, IRIS_BVH4_F32 = 1 /* 128-B nodes, f32 planes */, IRIS_BVH4_Q8 = 3 /* 64-B nodes, 8-bit planes (default) */ };
 
 typedef struct {
     int64_t n_vertices, n_triangles;
-    int32_t layout;        /* IRIS_BVH4_F32 | IRIS_BVH8_Q8 */
+    int32_t layout;        /* IRIS_BVH4_F32 | IRIS_BVH4_Q8 */
     int32_t n_nodes;       /* wide nodes */
     int32_t node_bytes;    /* bytes per node as stored in HBM */
     int32_t tri_bytes;     /* bytes per leaf-triangle record  */

@@ -7,7 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRIS_HIP_LIB") or os.path.join(_HERE, "libiris_hip.so")   # IRIS_HIP_LIB: A/B builds of the same ABI
 
-BVH_DEFAULT, BVH4_F32, BVH8_Q8 = 0, 1, 2
+BVH_DEFAULT, BVH4_F32, BVH4_Q8 = 0, 1, 3
 BAKE_AUTO, BAKE_PIXEL_PER_WAVE, BAKE_TILE_SORTED = 0, 1, 2
 
 

@@ -37,7 +37,7 @@ __device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int
 struct RayOut { float r0, g0, b0, r1, g1, b1; };
 
 // One (pixel, sample): sample the lobe, trace, shade.  Everything between the uniforms and Le*g stays in registers.
-template <bool SPEC, bool COUNT, int LDS_DEPTH = kStackLds>
+template <bool SPEC, bool COUNT, int LAYOUT, int LDS_DEPTH = kStackLds>
 __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int s, f3 x, f3 n, f3 w, f3 t, f3 b, uint64_t base,
                                                uint32_t* lds_stack, TraceStats* ts, uint32_t& n_rays) {
     float u0, u1;
@@ -53,7 +53,7 @@ __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int
     }
     // position + RayEpsilon*wi  (bake_shading.py:117, :180)
     f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-    Hit h = trace_bvh4<COUNT, LDS_DEPTH>(a.sc, o, wi, lds_stack, ts);
+    Hit h = trace_bvh4<LAYOUT, COUNT, LDS_DEPTH>(a.sc, o, wi, lds_stack, ts);
     if (COUNT) n_rays++;
     f3 pn = mk3(0.f, 0.f, 0.f);
     int64_t tri = -1;
@@ -76,8 +76,8 @@ __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int
 template <bool COUNT>
 __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats& ts, uint32_t n_rays) {
     if (COUNT) {
-        uint32_t v[5] = {n_rays, ts.nodes, ts.tris, ts.node_iters, ts.leaf_iters};
-        for (int k = 0; k < 5; ++k) {
+        uint32_t v[8] = {n_rays, ts.nodes, ts.tris, ts.node_iters, ts.leaf_iters, ts.sp_gt8, ts.sp_gt12, ts.sp_gt16};
+        for (int k = 0; k < 8; ++k) {
             uint32_t x = v[k];
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + k, (unsigned long long)x);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
 }
 
 // ------------------------------------------------------------------------------------------------------- v1
-template <bool SPEC, bool COUNT>
+template <bool SPEC, bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     const int lane = threadIdx.x & 63;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
         for (int r = 0; r < rounds; ++r) {
             const int s = r * 64 + sl;
             if (pvalid && s < spp) {
-                RayOut o = shade_sample<SPEC, COUNT>(a, p, s, x, n, w, t, b, base, s_stack + threadIdx.x, &ts, n_rays);
+                RayOut o = shade_sample<SPEC, COUNT, LAYOUT>(a, p, s, x, n, w, t, b, base, s_stack + threadIdx.x, &ts, n_rays);
                 a0x += o.r0; a0y += o.g0; a0z += o.b0;
                 if (SPEC) { a1x += o.r1; a1y += o.g1; a1z += o.b1; }
             }
@@ -152,11 +152,17 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     return m;
 }
 
-template <bool SPEC, bool COUNT>
-__global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
+#ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernel is compiled for (= workgroups per CU)
+#define IRIS_TILE_WAVES 5
+#endif
+#ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernel (deeper stacks spill to scratch; <0.4 % of rays exceed 12)
+#define IRIS_TILE_STACK 12
+#endif
+template <bool SPEC, bool COUNT, int LAYOUT>
+__global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
     // LDS: sorted ray list (16 KiB) + traversal stacks (24 KiB).  The stack region doubles as the sort's key / histogram
     // storage: the two uses are separated by workgroup barriers.
-    constexpr int kTileStack = kStackLds - 1;  // 16384 + 23552 + 8 B = 39944 B <= 160 KiB / 4 -> four workgroups per CU
+    constexpr int kTileStack = IRIS_TILE_STACK;  // 16384 B ray list + kTileStack KiB stacks + 8 B must fit 160 KiB / IRIS_TILE_WAVES
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void bake_tile_kernel(BakeArgs a) {
                 const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
                 f3 t, b;
                 normal_space(n, t, b);
-                RayOut o = shade_sample<SPEC, COUNT, kTileStack>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
+                RayOut o = shade_sample<SPEC, COUNT, LAYOUT, kTileStack>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
                 float4* q = res + (size_t)r * NC;
                 q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
                 if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);

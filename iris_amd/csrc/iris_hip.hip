@@ -93,30 +93,68 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
     if (nf >= (1 << 28)) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^28 triangles");
     for (int64_t i = 0; i < nf * 3; ++i)
         if (faces[i] < 0 || faces[i] >= nv) return fail(IRIS_ERR_ARG, "iris_scene_create: face index out of range");
-    if (layout == IRIS_BVH_DEFAULT) layout = IRIS_BVH4_F32;
-    if (layout != IRIS_BVH4_F32) return fail(IRIS_ERR_ARG, "iris_scene_create: unknown BVH layout");
+    if (layout == IRIS_BVH_DEFAULT) layout = IRIS_BVH4_Q8;
+    if (layout != IRIS_BVH4_F32 && layout != IRIS_BVH4_Q8) return fail(IRIS_ERR_ARG, "iris_scene_create: unknown BVH layout");
     HIP_TRY(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
-    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, 4);
+    int max_leaf = 4;
+    if (const char* e = getenv("IRIS_BVH_MAX_LEAF")) max_leaf = std::min(7, std::max(1, atoi(e)));   // tuning knob
+    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf);
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
 
-    // ---- encode nodes (BVH4_F32: 128 B) ----
+    // ---- encode nodes ----
     const size_t nn = bvh.nodes.size();
-    std::vector<float> nodes(nn * 32);
+    auto child_ref = [&](const WideNode& w, int s) -> uint32_t {
+        if (s >= w.n) return kEmptyRef;
+        if (w.child[s] >= 0) return (uint32_t)w.child[s];
+        return kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
+    };
+    const int node_floats = layout == IRIS_BVH4_Q8 ? 16 : 32;
+    std::vector<float> nodes(nn * node_floats);
     for (size_t i = 0; i < nn; ++i) {
         const WideNode& w = bvh.nodes[i];
-        float* p = nodes.data() + i * 32;
-        for (int s = 0; s < 4; ++s) {
-            p[0 + s] = w.lo[s][0]; p[4 + s] = w.hi[s][0];
-            p[8 + s] = w.lo[s][1]; p[12 + s] = w.hi[s][1];
-            p[16 + s] = w.lo[s][2]; p[20 + s] = w.hi[s][2];
-            uint32_t ref = kEmptyRef;
-            if (s < w.n) {
-                if (w.child[s] >= 0) ref = (uint32_t)w.child[s];
-                else ref = kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
+        float* p = nodes.data() + i * node_floats;
+        if (layout == IRIS_BVH4_F32) {   // 128 B: lox[4] hix[4] loy[4] hiy[4] loz[4] hiz[4] ref[4] pad[4]
+            for (int s = 0; s < 4; ++s) {
+                p[0 + s] = w.lo[s][0]; p[4 + s] = w.hi[s][0];
+                p[8 + s] = w.lo[s][1]; p[12 + s] = w.hi[s][1];
+                p[16 + s] = w.lo[s][2]; p[20 + s] = w.hi[s][2];
+                uint32_t ref = child_ref(w, s);
+                std::memcpy(&p[24 + s], &ref, 4);
+                p[28 + s] = 0.f;
             }
-            std::memcpy(&p[24 + s], &ref, 4);
-            p[28 + s] = 0.f;
+        } else {                         // 64 B: origin.xyz, exps | qlo_x qlo_y qlo_z qhi_x | qhi_y qhi_z - - | ref[4]
+            float org[3], hi3[3];
+            for (int k = 0; k < 3; ++k) {
+                org[k] = INFINITY; hi3[k] = -INFINITY;
+                for (int s = 0; s < w.n; ++s) { org[k] = std::min(org[k], w.lo[s][k]); hi3[k] = std::max(hi3[k], w.hi[s][k]); }
+                if (w.n == 0) { org[k] = 0.f; hi3[k] = 0.f; }
+            }
+            uint32_t ebytes = 0;
+            uint8_t q[6][4];   // planes lo_x lo_y lo_z hi_x hi_y hi_z
+            for (int k = 0; k < 3; ++k) {
+                const double ext = (double)hi3[k] - (double)org[k];
+                int e = -126;
+                if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
+                while (std::ldexp(255.0, e) < ext) ++e;                       // 255 * 2^e must cover the extent
+                const double sc = std::ldexp(1.0, e);
+                ebytes |= (uint32_t)(e + 127) << (8 * k);
+                for (int s = 0; s < 4; ++s) {
+                    if (s >= w.n) { q[k][s] = 255; q[3 + k][s] = 0; continue; }   // inverted box: never hit
+                    int lo = (int)std::floor(((double)w.lo[s][k] - (double)org[k]) / sc);
+                    int hi = (int)std::ceil(((double)w.hi[s][k] - (double)org[k]) / sc);
+                    lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
+                    while (lo > 0 && (double)org[k] + lo * sc > (double)w.lo[s][k]) --lo;       // decoded box must contain the f32 box
+                    while (hi < 255 && (double)org[k] + hi * sc < (double)w.hi[s][k]) ++hi;
+                    if ((double)org[k] + hi * sc < (double)w.hi[s][k]) return fail(IRIS_ERR_BUILD, "iris_scene_create: node quantisation failed");
+                    q[k][s] = (uint8_t)lo; q[3 + k][s] = (uint8_t)hi;
+                }
+            }
+            p[0] = org[0]; p[1] = org[1]; p[2] = org[2];
+            std::memcpy(&p[3], &ebytes, 4);
+            std::memcpy(&p[4], q[0], 4); std::memcpy(&p[5], q[1], 4); std::memcpy(&p[6], q[2], 4); std::memcpy(&p[7], q[3], 4);
+            std::memcpy(&p[8], q[4], 4); std::memcpy(&p[9], q[5], 4); p[10] = 0.f; p[11] = 0.f;
+            for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }
     }
     // ---- encode leaf triangles (48 B) ----
@@ -141,10 +179,11 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
     s->dev.tris = (const float4*)s->d_tris;
     s->dev.n_nodes = (int)nn;
     s->dev.n_tris = (int)nt;
+    s->dev.layout = layout == IRIS_BVH4_Q8 ? kLayoutQ8 : kLayoutF32;
     s->dev.phase_min = kPhaseMin;
     if (const char* e = getenv("IRIS_PHASE_MIN")) s->dev.phase_min = atoi(e);  // tuning knob (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
-    s->info.node_bytes = 128; s->info.tri_bytes = 48; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
+    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 48; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
     s->info.sah_cost = bvh.sah_cost;
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
@@ -316,13 +355,14 @@ extern "C" IRIS_API int iris_raygen_synthetic(float focal, const float c2w[12], 
 // ======================================================================================================
 // a2 ray_intersect
 // ======================================================================================================
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev sc, const float* __restrict__ xs, const float* __restrict__ ds,
                                                            int64_t B, float* __restrict__ pos, float* __restrict__ nrm,
                                                            float* __restrict__ uv, int64_t* __restrict__ idx, uint8_t* __restrict__ valid) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
         f3 o = ld3(xs + i * 3), d = ld3(ds + i * 3);
-        Hit h = trace_bvh4(sc, o, d, s_stack + threadIdx.x);
+        Hit h = trace_bvh4<LAYOUT>(sc, o, d, s_stack + threadIdx.x);
         if (h.slot >= 0) {
             f3 p0, p1, p2;
             hit_vertices(sc, h, p0, p1, p2);
@@ -348,8 +388,12 @@ extern "C" IRIS_API int iris_intersect(const iris_scene* s, const float* xs, con
                               int64_t* idx, uint8_t* valid, iris_stream_t stream) {
     if (!s || B < 0 || (B > 0 && (!xs || !ds))) return fail(IRIS_ERR_ARG, "iris_intersect: bad arguments");
     if (B == 0) return IRIS_OK;
-    hipLaunchKernelGGL(intersect_kernel, dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
-                       pos, nrm, uv, idx, valid);
+    if (s->dev.layout == kLayoutQ8)
+        hipLaunchKernelGGL(intersect_kernel<kLayoutQ8>, dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
+                           pos, nrm, uv, idx, valid);
+    else
+        hipLaunchKernelGGL(intersect_kernel<kLayoutF32>, dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
+                           pos, nrm, uv, idx, valid);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
@@ -477,7 +521,7 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // ======================================================================================================
 // a3..a7 fused bake kernels (iris_bake.h)
 // ======================================================================================================
-static int bake_grid_blocks() { return num_cus() * 4; }  // 4 resident 256-thread workgroups per CU (VGPR- and LDS-bound)
+static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
 
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
     if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
@@ -516,24 +560,27 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
         const int64_t n_tiles = (P + tile_px - 1) / tile_px;
         const int grid = (int)std::min<int64_t>(blocks, n_tiles);
-        if (stats) {
-            if (spec) hipLaunchKernelGGL((bake_tile_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-            else hipLaunchKernelGGL((bake_tile_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        } else {
-            if (spec) hipLaunchKernelGGL((bake_tile_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-            else hipLaunchKernelGGL((bake_tile_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
-        }
+#define IRIS_LAUNCH_BAKE(KERNEL, GRID)                                                                                            \
+    do {                                                                                                                         \
+        const bool q8 = a.sc.layout == kLayoutQ8;                                                                                \
+        if (stats) {                                                                                                             \
+            if (spec) { if (q8) hipLaunchKernelGGL((KERNEL<true, true, kLayoutQ8>), dim3(GRID), dim3(kBlock), 0, st, a);          \
+                        else hipLaunchKernelGGL((KERNEL<true, true, kLayoutF32>), dim3(GRID), dim3(kBlock), 0, st, a); }          \
+            else      { if (q8) hipLaunchKernelGGL((KERNEL<false, true, kLayoutQ8>), dim3(GRID), dim3(kBlock), 0, st, a);         \
+                        else hipLaunchKernelGGL((KERNEL<false, true, kLayoutF32>), dim3(GRID), dim3(kBlock), 0, st, a); }         \
+        } else {                                                                                                                 \
+            if (spec) { if (q8) hipLaunchKernelGGL((KERNEL<true, false, kLayoutQ8>), dim3(GRID), dim3(kBlock), 0, st, a);         \
+                        else hipLaunchKernelGGL((KERNEL<true, false, kLayoutF32>), dim3(GRID), dim3(kBlock), 0, st, a); }         \
+            else      { if (q8) hipLaunchKernelGGL((KERNEL<false, false, kLayoutQ8>), dim3(GRID), dim3(kBlock), 0, st, a);        \
+                        else hipLaunchKernelGGL((KERNEL<false, false, kLayoutF32>), dim3(GRID), dim3(kBlock), 0, st, a); }        \
+        }                                                                                                                        \
+    } while (0)
+        IRIS_LAUNCH_BAKE(bake_tile_kernel, grid);
     } else {
         const int ppw = (spp < 64 && (spp & (spp - 1)) == 0) ? 64 / spp : 1;
         const int64_t n_groups = (P + ppw - 1) / ppw;
         const int grid = grid_for(n_groups * 64, kBlock, num_cus() * 6);
-        if (stats) {
-            if (spec) hipLaunchKernelGGL((bake_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-            else hipLaunchKernelGGL((bake_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        } else {
-            if (spec) hipLaunchKernelGGL((bake_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-            else hipLaunchKernelGGL((bake_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
-        }
+        IRIS_LAUNCH_BAKE(bake_kernel, grid);
     }
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
@@ -617,7 +664,8 @@ extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e,
     a.sc = sc->dev; a.em = e->dev; a.es = e->sample; a.N = N;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
     a.coef1 = coef1; a.e1 = e1;
-    hipLaunchKernelGGL(pt_nee_kernel, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pt_nee_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
@@ -633,7 +681,8 @@ extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* po
     a.sc = sc->dev; a.N = N;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
     a.wi_out = wi; a.brdf_pdf = pdf; a.brdf_w = weight; a.pos_next = pos_next; a.nrm_next = nrm_next; a.tri_next = tri_next; a.valid_next_hit = valid;
-    hipLaunchKernelGGL(pt_brdf_trace_kernel, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

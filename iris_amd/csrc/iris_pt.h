@@ -109,6 +109,7 @@ __device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
 
 // utils/path_tracing.py:357-382: emitter sampling, visibility ray, geometry term, eval_brdf, power-2 MIS.
 // term1 = coef1 * radiance[e1]   (e1 = -1 -> no contribution)
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
         f3 wi; float emit_pdf; int64_t emit_tri;
         sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], x, wi, emit_pdf, emit_tri);
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-        Hit h = trace_bvh4(a.sc, o, wi, s_stack + threadIdx.x);
+        Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
         const bool emit_valid = h.slot >= 0;
         int ord = -1;
         float G = 1.f;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
 }
 
 // utils/path_tracing.py:384-392: BRDF sampling + next intersection
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
         f3 wi, w; float pdf;
         sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-        Hit h = trace_bvh4(a.sc, o, wi, s_stack + threadIdx.x);
+        Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
         f3 pn = mk3(0.f, 0.f, 0.f), nn = mk3(0.f, 0.f, 0.f);
         int64_t tri = -1;
         if (h.slot >= 0) {

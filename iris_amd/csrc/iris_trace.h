@@ -18,6 +18,7 @@ struct SceneDev {
     int n_nodes;
     int n_tris;
     int phase_min;  // wave-level phase scheduling threshold (see trace_bvh4)
+    int layout;     // kLayoutF32 | kLayoutQ8
 };
 
 struct Hit {
@@ -80,6 +81,7 @@ struct TraceStats {
     uint32_t tris = 0;        // triangle tests of this lane
     uint32_t node_iters = 0;  // wave-level executions of the node step (counted by the first active lane)
     uint32_t leaf_iters = 0;  // wave-level executions of the triangle test
+    uint32_t sp_gt8 = 0, sp_gt12 = 0, sp_gt16 = 0;  // rays whose stack ever exceeded 8 / 12 / 16 entries
 };
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
@@ -92,7 +94,13 @@ __device__ __forceinline__ bool first_active_lane() {
 // keeping the whole wave in a nearly empty phase).  Per-lane results do not depend on the schedule.
 constexpr int kPhaseMin = 16;
 
-template <bool COUNT = false, int LDS_DEPTH = kStackLds>
+// Node layouts (iris_hip.h): BVH4_F32 = 128-B node with f32 planes (7 dwordx4 per visit); BVH4_Q8 = 64-B node
+// {origin.xyz, biased exponents | qlo_x qlo_y qlo_z qhi_x | qhi_y qhi_z - - | ref[4]} with 8-bit planes relative to the node's own
+// box (4 dwordx4 per visit): plane = origin + q * 2^e, lo rounded down / hi rounded up, so the decoded box contains the f32 box.
+constexpr int kLayoutF32 = 1, kLayoutQ8 = 3;
+__device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xffu); }
+
+template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds>
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr) {
     Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
     const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
@@ -101,6 +109,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
     Stack<LDS_DEPTH> st; st.lds = lds_stack; st.sp = 0;
     uint32_t cur = 0;  // root
     int k = 0;         // triangles of the current leaf already tested
+    int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
         // ---------------- node phase
@@ -111,11 +120,34 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
             if (n_node < kPhaseMinRt && __popcll(__ballot(cur != kEmptyRef && (cur & kLeafBit))) >= kPhaseMinRt) break;
             if (at_node) {
                 if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
+                float k0, k1, k2, k3;
+                uint32_t r0, r1, r2, r3;
+                if (LAYOUT == kLayoutQ8) {
+                    const uint4* n = reinterpret_cast<const uint4*>(sc.nodes) + (int64_t)cur * 4;
+                    const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
+                    r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
+                    // per-axis: t(q) = q * (2^e * idir) + (origin * idir - o * idir)
+                    const float ax = __uint_as_float((hd.w & 0xffu) << 23) * ix, ay = __uint_as_float(((hd.w >> 8) & 0xffu) << 23) * iy,
+                                az = __uint_as_float(((hd.w >> 16) & 0xffu) << 23) * iz;
+                    const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
+                    const uint32_t nxq = px ? q1.x : q1.w, fxq = px ? q1.w : q1.x;
+                    const uint32_t nyq = py ? q1.y : q2.x, fyq = py ? q2.x : q1.y;
+                    const uint32_t nzq = pz ? q1.z : q2.y, fzq = pz ? q2.y : q1.z;
+#define IRIS_SLABQ(K, C)                                                                                                          \
+    {                                                                                                                             \
+        float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), ax, bx), fmaf(ubyte(nyq, C), ay, by)), fmaxf(fmaf(ubyte(nzq, C), az, bz), 0.f)); \
+        float tf = fminf(fminf(fmaf(ubyte(fxq, C), ax, bx), fmaf(ubyte(fyq, C), ay, by)), fminf(fmaf(ubyte(fzq, C), az, bz), h.t)); \
+        K = tn <= tf ? tn : INFINITY;                                                                                             \
+    }
+                    IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
+#undef IRIS_SLABQ
+                    // NB: hipcc sinks the child-reference load (n[3]) behind the hit test; forcing it up front with the other
+                    // loads was measured 8 % SLOWER (the vector-memory pipe is the bottleneck, and nodes without a hit skip it)
+                } else {
                 const float4* n = sc.nodes + (int64_t)cur * 8;
                 const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
                 const float4 rf = n[6];
-                float k0, k1, k2, k3;
-                uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+                r0 = __float_as_uint(rf.x); r1 = __float_as_uint(rf.y); r2 = __float_as_uint(rf.z); r3 = __float_as_uint(rf.w);
 #define IRIS_SLAB(K, C)                                                                                               \
     {                                                                                                                 \
         float tn = fmaxf(fmaxf(fmaf(px ? lox.C : hix.C, ix, nx), fmaf(py ? loy.C : hiy.C, iy, ny)),                   \
@@ -126,12 +158,14 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
     }
                 IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
 #undef IRIS_SLAB
+                }
                 IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
                 if (k0 < INFINITY) {
                     cur = r0;
                     if (k3 < INFINITY) st.push(r3);
                     if (k2 < INFINITY) st.push(r2);
                     if (k1 < INFINITY) st.push(r1);
+                    if (COUNT) max_sp = max(max_sp, st.sp);
                 } else {
                     cur = st.sp > 0 ? st.pop() : kEmptyRef;
                 }
@@ -152,6 +186,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
         }
         if (__ballot(cur != kEmptyRef) == 0) break;
     }
+    if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; }
     return h;
 }
 

@@ -186,16 +186,19 @@ def _random_soup(rng, n):
 
 
 def _check_intersect(dev, oracle_mod, verts, faces, o, d, brute):
+    from iris_amd import _lib as L
     from iris_amd.utils.path_tracing import Scene, ray_intersect
-    sc = Scene(verts, faces, device=dev)
     osc = oracle_mod.Scene(verts, faces)
-    p, n, uv, idx, valid = ray_intersect(sc, T(o, dev), T(d, dev))
     op, on, ouv, oidx, ovalid = osc.ray_intersect(o, d, brute=brute)
-    np.testing.assert_array_equal(N(idx), oidx)        # index work: exact
-    np.testing.assert_array_equal(N(valid), ovalid)
-    np.testing.assert_array_equal(N(uv), ouv)          # same IEEE op sequence: exact
-    np.testing.assert_array_equal(N(p), op)
-    np.testing.assert_array_equal(N(n), on)
+    for layout in (L.BVH4_Q8, L.BVH4_F32):             # both node layouts must give the brute-force answer
+        sc = Scene(verts, faces, device=dev, layout=layout)
+        assert sc.info()["layout"] == layout
+        p, n, uv, idx, valid = ray_intersect(sc, T(o, dev), T(d, dev))
+        np.testing.assert_array_equal(N(idx), oidx)        # index work: exact
+        np.testing.assert_array_equal(N(valid), ovalid)
+        np.testing.assert_array_equal(N(uv), ouv)          # same IEEE op sequence: exact
+        np.testing.assert_array_equal(N(p), op)
+        np.testing.assert_array_equal(N(n), on)
     return ovalid.mean()
 
 
