@@ -173,7 +173,7 @@ def main():
         nP = g["position"].shape[0]
         sel = torch.arange(nP, device=dev)
         sel = sel[(sel // 8192) % 16 == 3] if nP > 16 * 8192 else sel
-        stats = torch.zeros(8, device=dev, dtype=torch.int64)
+        stats = torch.zeros(16, device=dev, dtype=torch.int64)
         for l in range(1, 7):
             bs.bake_specular(scene, emitter, g["position"][sel], g["normal"][sel], g["wo"][sel], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"][sel], stats=stats, variant=args.variant)
         torch.cuda.synchronize()
@@ -187,6 +187,7 @@ def main():
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                               "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
                               "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3), "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
+                              "mean_over_max_ray_length_in_wave": round((st[1] + st[2]) / max(st[8], 1), 3),
                               "stack_depth_frac_gt_8_12_16": [round(st[5] / st[0], 4), round(st[6] / st[0], 4), round(st[7] / st[0], 5)],
                               "launch_ms": round(avg_ms, 3), "launch_ms_by_roughness_level": [round(float(np.mean(ms[i::len([l for l in lobes if l > 0])])), 2) for i in range(len([l for l in lobes if l > 0]))],
                               "launches": len(ms), "mrays_per_s_kernel": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1)}

@@ -119,7 +119,7 @@ enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED =
  * (row = pixel*spp + sample), or NULL -> in-kernel Philox4x32-10 keyed by (seed, pix_id[p]*spp+s, stream);
  * pix_id (P) int32 nullable (defaults to p) makes the sample set independent of how pixels are sharded.
  * Ld/Ls0/Ls1: (P,3) = mean over spp of Le, Le*g0, Le*g1.  tri_next (P*spp) int64 nullable debug output.
- * stats: nullable device uint64[8]; when given, an INSTRUMENTED (slower) build of the kernel adds {rays, BVH node
+ * stats: nullable device uint64[16]; when given, an INSTRUMENTED (slower) build of the kernel adds {rays, BVH node
  * visits, triangle tests, wave-level node steps, wave-level triangle steps} to it (used to price the roofline).
  * workspace: device scratch of iris_bake_workspace_bytes() bytes for the tile-sorted kernel (per-ray results parked
  * between the trace and the reduction phases); NULL selects the pixel-per-wave kernel.  Both give identical bits. */

@@ -53,8 +53,15 @@ __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int
     }
     // position + RayEpsilon*wi  (bake_shading.py:117, :180)
     f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
+    const uint32_t steps0 = COUNT ? ts->nodes + ts->tris : 0;
     Hit h = trace_bvh4<LAYOUT, COUNT, LDS_DEPTH>(a.sc, o, wi, lds_stack, ts);
-    if (COUNT) n_rays++;
+    if (COUNT) {
+        n_rays++;
+        // tail statistic: the wave lasts as long as its longest ray -> sum over waves of 64 * max(steps per lane)
+        uint32_t mine = ts->nodes + ts->tris - steps0, mx = mine;
+        for (int m = 1; m < 64; m <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m));
+        if (first_active_lane()) ts->max_steps64 += (unsigned long long)mx * 64ull;
+    }
     f3 pn = mk3(0.f, 0.f, 0.f);
     int64_t tri = -1;
     if (h.slot >= 0) {
@@ -82,6 +89,9 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + k, (unsigned long long)x);
         }
+        unsigned long long y = ts.max_steps64;
+        for (int m = 1; m < 64; m <<= 1) y += __shfl_xor(y, m);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 8, y);
     }
 }
 

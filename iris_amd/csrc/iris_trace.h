@@ -82,6 +82,7 @@ struct TraceStats {
     uint32_t node_iters = 0;  // wave-level executions of the node step (counted by the first active lane)
     uint32_t leaf_iters = 0;  // wave-level executions of the triangle test
     uint32_t sp_gt8 = 0, sp_gt12 = 0, sp_gt16 = 0;  // rays whose stack ever exceeded 8 / 12 / 16 entries
+    unsigned long long max_steps64 = 0;             // sum over wave-chunks of 64 * (longest ray of the chunk, in node+triangle steps)
 };
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
