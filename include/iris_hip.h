@@ -156,19 +156,28 @@ IRIS_API int iris_pt_jitter(const float *rays_d, const float *dxdu, const float 
                    iris_stream_t);
 /* :344  eval_emitter(position, wi, triangle_idx) with the radiance gather factored out: e0 = emitter ordinal or -1 */
 IRIS_API int iris_pt_primary_emit(const iris_emitter *, const int64_t *tri, int64_t N, int32_t *e0, uint8_t *valid_next, iris_stream_t);
-/* :357-382  emitter sampling + visibility ray + geometry term + eval_brdf + MIS -> term1 = coef1 * radiance[e1] */
+/* :357-382  emitter sampling + visibility ray + geometry term + eval_brdf + MIS -> term1 = coef1 * radiance[e1].
+ * g_eps / pdf_eps / mis_eps: the clamp_min constants of the caller: 1e-6,1e-6,1e-6 in path_tracing_single (:370,:373,:379),
+ * 1e-12,1e-12,none(<=0) in trace_indirect (:445,:448,:453). */
 IRIS_API int iris_pt_nee(const iris_scene *, const iris_emitter *, const float *pos, const float *nrm, const float *wo, const float *albedo,
                 const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *coef1, int32_t *e1,
-                iris_stream_t);
-/* :384-391  sample_brdf + next intersection */
+                float g_eps, float pdf_eps, float mis_eps, iris_stream_t);
+/* :384-391  lobe sampling + next intersection.  lobe 0: sample_brdf(s1,s2,wo,normal,mat); lobe 1: sample_diffuse(s2,normal)
+ * (path_tracing_det_diff :93-97, weight 1); lobe 2: sample_specular(s2,wo,normal,lobe_roughness) (path_tracing_det_spec :174-178),
+ * weight = (g0,g1,0). */
 IRIS_API int iris_pt_brdf_trace(const iris_scene *, const float *pos, const float *nrm, const float *wo, const float *albedo,
                        const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *wi,
                        float *pdf, float *weight, float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid,
-                       iris_stream_t);
+                       int lobe, float lobe_roughness, iris_stream_t);
 /* :394-404  eval_emitter(..., mat_next.roughness, 0.0) + geometry term + MIS -> term2 = coef2 * radiance[e2] + const2 */
 IRIS_API int iris_pt_brdf_finish(const iris_emitter *, const iris_slf *, const float *pos, const float *pos_next, const float *nrm_next,
                         const float *wi, const int64_t *tri_next, const float *roughness_next, const float *pdf, const float *weight,
-                        int64_t N, float *coef2, float *const2, int32_t *e2, iris_stream_t);
+                        int64_t N, float *coef2, float *const2, int32_t *e2, uint8_t *valid_next /*nullable*/, float trace_roughness,
+                        float g_eps, iris_stream_t);
+/* trace_indirect's accumulation (utils/path_tracing.py:454-456,:462,:484-486): L[rows[i]] += throughput[i] * (coef[i]*radiance[e[i]]
+ * + cst[i]) with NaN -> 0, then throughput[i] *= weight[i].  rows, throughput, e/coef, cst, weight are each nullable. */
+IRIS_API int iris_pt_apply(float *L, const int32_t *rows, float *throughput, const float *radiance, const int32_t *e, const float *coef,
+                  const float *cst, const float *weight, int64_t N, int nan_to_zero, iris_stream_t);
 /* :406  L (B,3) = mean over spp; path_of (B*spp) maps a path to its row in the compacted stage arrays (or -1).
  * radiance: the (n_rad,3) parameter tensor itself (model/emitter.py:268). */
 IRIS_API int iris_pt_accumulate_fwd(const float *radiance, const int32_t *e0, const int32_t *path_of, const int32_t *e1, const float *coef1,

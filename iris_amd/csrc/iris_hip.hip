@@ -656,14 +656,14 @@ extern "C" IRIS_API int iris_pt_primary_emit(const iris_emitter* e, const int64_
 }
 extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e, const float* pos, const float* nrm, const float* wo, const float* albedo,
                            const float* roughness, const float* metallic, const float* s1, const float* s2, int64_t N, float* coef1, int32_t* e1,
-                           iris_stream_t stream) {
+                           float g_eps, float pdf_eps, float mis_eps, iris_stream_t stream) {
     if (!sc || !e || !e->can_sample) return fail(IRIS_ERR_ARG, "iris_pt_nee: scene / emitter (with vertices + cdf) required");
     if (N < 0 || (N > 0 && (!pos || !nrm || !wo || !albedo || !roughness || !metallic || !s1 || !s2 || !coef1 || !e1))) return fail(IRIS_ERR_ARG, "iris_pt_nee: bad arguments");
     if (N == 0) return IRIS_OK;
     PtArgs a{};
     a.sc = sc->dev; a.em = e->dev; a.es = e->sample; a.N = N;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
-    a.coef1 = coef1; a.e1 = e1;
+    a.coef1 = coef1; a.e1 = e1; a.g_eps = g_eps; a.pdf_eps = pdf_eps; a.mis_eps = mis_eps;
     if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_nee_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -672,15 +672,17 @@ extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e,
 extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* pos, const float* nrm, const float* wo, const float* albedo,
                                   const float* roughness, const float* metallic, const float* s1, const float* s2, int64_t N, float* wi,
                                   float* pdf, float* weight, float* pos_next, float* nrm_next, int64_t* tri_next, uint8_t* valid,
-                                  iris_stream_t stream) {
-    if (!sc || N < 0 || (N > 0 && (!pos || !nrm || !wo || !albedo || !roughness || !metallic || !s1 || !s2 || !wi || !pdf || !weight || !pos_next ||
-                                   !nrm_next || !tri_next || !valid)))
+                                  int lobe, float lobe_roughness, iris_stream_t stream) {
+    if (!sc || N < 0 || lobe < 0 || lobe > 2 ||
+        (N > 0 && (!pos || !nrm || !wo || !s2 || !wi || !pdf || !weight || !pos_next || !nrm_next || !tri_next || !valid ||
+                   (lobe == 0 && (!albedo || !roughness || !metallic || !s1)))))
         return fail(IRIS_ERR_ARG, "iris_pt_brdf_trace: bad arguments");
     if (N == 0) return IRIS_OK;
     PtArgs a{};
     a.sc = sc->dev; a.N = N;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
     a.wi_out = wi; a.brdf_pdf = pdf; a.brdf_w = weight; a.pos_next = pos_next; a.nrm_next = nrm_next; a.tri_next = tri_next; a.valid_next_hit = valid;
+    a.lobe = lobe; a.lobe_rough = lobe_roughness;
     if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -688,14 +690,15 @@ extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* po
 }
 extern "C" IRIS_API int iris_pt_brdf_finish(const iris_emitter* e, const iris_slf* slf, const float* pos, const float* pos_next, const float* nrm_next,
                                    const float* wi, const int64_t* tri_next, const float* roughness_next, const float* pdf, const float* weight,
-                                   int64_t N, float* coef2, float* const2, int32_t* e2, iris_stream_t stream) {
+                                   int64_t N, float* coef2, float* const2, int32_t* e2, uint8_t* valid_next, float trace_roughness, float g_eps,
+                                   iris_stream_t stream) {
     if (!e || !slf || N < 0 || (N > 0 && (!pos || !pos_next || !nrm_next || !wi || !tri_next || !roughness_next || !pdf || !weight || !coef2 || !const2 || !e2)))
         return fail(IRIS_ERR_ARG, "iris_pt_brdf_finish: bad arguments");
     if (N == 0) return IRIS_OK;
     PtArgs a{};
     a.em = e->dev; a.slf = slf->dev; a.N = N;
     a.pos = pos; a.pos_n_in = pos_next; a.nrm_n_in = nrm_next; a.wi_in = wi; a.tri_n_in = tri_next; a.rough_next = roughness_next; a.pdf_in = pdf; a.w_in = weight;
-    a.coef2 = coef2; a.const2 = const2; a.e2 = e2;
+    a.coef2 = coef2; a.const2 = const2; a.e2 = e2; a.valid_next_hit = valid_next; a.trace_rough = trace_roughness; a.g_eps = g_eps;
     LAUNCH1D(pt_brdf_finish_kernel, N, stream, a);
     return IRIS_OK;
 }
@@ -712,5 +715,13 @@ extern "C" IRIS_API int iris_pt_accumulate_bwd(const float* gL, const int32_t* e
     if (B < 0 || spp < 1 || (B > 0 && (!gL || !e0 || !path_of || !g_radiance))) return fail(IRIS_ERR_ARG, "iris_pt_accumulate_bwd: bad arguments");
     if (B == 0) return IRIS_OK;
     LAUNCH1D(pt_accumulate_bwd_kernel, B * spp, stream, gL, e0, path_of, e1, coef1, e2, coef2, B, spp, g_radiance);
+    return IRIS_OK;
+}
+
+extern "C" IRIS_API int iris_pt_apply(float* L, const int32_t* rows, float* throughput, const float* radiance, const int32_t* e, const float* coef,
+                             const float* cst, const float* weight, int64_t N, int nan_to_zero, iris_stream_t stream) {
+    if (N < 0 || (N > 0 && (!L || (e && (!radiance || !coef))))) return fail(IRIS_ERR_ARG, "iris_pt_apply: bad arguments");
+    if (N == 0) return IRIS_OK;
+    LAUNCH1D(pt_apply_kernel, N, stream, L, rows, throughput, radiance, e, coef, cst, weight, N, nan_to_zero);
     return IRIS_OK;
 }

@@ -100,6 +100,10 @@ struct PtArgs {
     // finish inputs/outputs
     const float *wi_in, *pdf_in, *w_in, *pos_n_in, *nrm_n_in, *rough_next; const int64_t* tri_n_in;
     float *coef2, *const2; int32_t* e2;
+    // variant parameters: path_tracing_single (:320-407) clamps with 1e-6, trace_indirect (:409-502) with 1e-12 and no MIS clamp
+    float g_eps, pdf_eps, mis_eps;   // mis_eps <= 0: no clamp_min on the NEE MIS denominator
+    float trace_rough;               // eval_emitter's trace_roughness in the finish stage
+    int lobe; float lobe_rough;      // brdf_trace: 0 = sample_brdf, 1 = sample_diffuse (weight 1), 2 = sample_specular(lobe_rough) -> weight (g0,g1,0)
 };
 
 __device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
@@ -132,17 +136,21 @@ __global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
             ord = a.em.emit_ord[h.id];                           // eval_emitter(emit_position, wi, triangle_idx): Le = radiance[ord] if emitter
             const f3 dlt = sub3(ep, x);
             const float d2 = (dlt.x * dlt.x + dlt.y * dlt.y) + dlt.z * dlt.z;
-            G = fabsf(t_dot(mk3(-wi.x, -wi.y, -wi.z), en)) / fmaxf(d2, 1e-6f);
+            G = fabsf(t_dot(mk3(-wi.x, -wi.y, -wi.z), en)) / fmaxf(d2, a.g_eps);
         }
         f3 brdf; float brdf_pdf;
         eval_brdf1(wi, wo, n, load_mat(a, i), brdf, brdf_pdf);
         brdf_pdf = brdf_pdf * G;
         float w_mis = 0.f;
-        if (emit_pdf > 0.f && !isinf(brdf_pdf)) w_mis = emit_pdf * emit_pdf / fmaxf(emit_pdf * emit_pdf + brdf_pdf * brdf_pdf, 1e-6f);
+        if (emit_pdf > 0.f && !isinf(brdf_pdf)) {
+            float den = emit_pdf * emit_pdf + brdf_pdf * brdf_pdf;
+            if (a.mis_eps > 0.f) den = fmaxf(den, a.mis_eps);
+            w_mis = emit_pdf * emit_pdf / den;
+        }
         if (isinf(emit_pdf) || brdf_pdf == 0.f) w_mis = 1.f;
-        // emit_weight = Le * emit_vis * G / clamp(emit_pdf,1e-6); L += emit_brdf * emit_weight * w_mis
+        // emit_weight = Le * emit_vis * G / clamp(emit_pdf,eps); L += emit_brdf * emit_weight * w_mis
         const float s = (emit_vis ? 1.f : 0.f);
-        const float ew = G / fmaxf(emit_pdf, 1e-6f);
+        const float ew = G / fmaxf(emit_pdf, a.pdf_eps);
         // coefficient applied to radiance[ord]: ((1*vis)*G/pdf) then *brdf then *w_mis, in the reference's evaluation order
         st3(a.coef1 + i * 3, mk3(brdf.x * (s * ew) * w_mis, brdf.y * (s * ew) * w_mis, brdf.z * (s * ew) * w_mis));
         a.e1[i] = (emit_valid && ord >= 0) ? ord : -1;
@@ -156,7 +164,22 @@ __global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
         const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
         f3 wi, w; float pdf;
-        sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
+        if (a.lobe == 0) {
+            sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
+        } else {
+            f3 t, b;
+            normal_space(n, t, b);
+            if (a.lobe == 1) {                                   // BaseBRDF.sample_diffuse (model/brdf.py:78-88)
+                wi = diffuse_sampler(a.s2[i * 2], a.s2[i * 2 + 1], n, t, b);
+                pdf = relu(t_dot(n, wi)) / kPi;
+                w = mk3(1.f, 1.f, 1.f);
+            } else {                                             // BaseBRDF.sample_specular (model/brdf.py:112-136)
+                wi = specular_sampler(a.s2[i * 2], a.s2[i * 2 + 1], a.lobe_rough, wo, n, t, b);
+                SpecW sw = specular_weights(wi, wo, n, a.lobe_rough, true);
+                pdf = sw.pdf;
+                w = mk3(sw.g0, sw.g1, 0.f);
+            }
+        }
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
         Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
         f3 pn = mk3(0.f, 0.f, 0.f), nn = mk3(0.f, 0.f, 0.f);
@@ -189,14 +212,15 @@ __global__ void pt_brdf_finish_kernel(PtArgs a) {
         if (is_area) emit_pdf = a.em.emitter_pdf / fmaxf(a.em.area[ord], 1e-12f);
         bool valid_next = (!is_area) && vis;
         f3 slf = mk3(0.f, 0.f, 0.f);
-        if ((!is_area) && vis && a.rough_next[i] > 0.0f) {
+        if ((!is_area) && vis && a.rough_next[i] > a.trace_rough) {
             slf = slf_forward(a.slf, pn);
             if ((slf.x + slf.y) + slf.z > 0.f) valid_next = false;
         }
         const f3 dlt = sub3(x, pn);
         const float d2 = (dlt.x * dlt.x + dlt.y * dlt.y) + dlt.z * dlt.z;
-        float G = fabsf(t_dot(mk3(-nn.x, -nn.y, -nn.z), wi)) / fmaxf(d2, 1e-6f);
+        float G = fabsf(t_dot(mk3(-nn.x, -nn.y, -nn.z), wi)) / fmaxf(d2, a.g_eps);
         if (!valid_next) G = 1.f;                                 // torch.where(valid_next, G, 1)
+        if (a.valid_next_hit) a.valid_next_hit[i] = valid_next ? 1 : 0;
         const float brdf_pdf = a.pdf_in[i] * G;
         float w_mis = 0.f;
         if (brdf_pdf > 0.f && !isinf(emit_pdf)) w_mis = brdf_pdf * brdf_pdf / (emit_pdf * emit_pdf + brdf_pdf * brdf_pdf);
@@ -249,6 +273,22 @@ __global__ void pt_accumulate_bwd_kernel(const float* __restrict__ gL, const int
             if (e1[j] >= 0) { float* q = g_radiance + (int64_t)e1[j] * 3; f3 c = ld3(coef1 + (int64_t)j * 3); atomicAdd(q, g.x * c.x); atomicAdd(q + 1, g.y * c.y); atomicAdd(q + 2, g.z * c.z); }
             if (e2[j] >= 0) { float* q = g_radiance + (int64_t)e2[j] * 3; f3 c = ld3(coef2 + (int64_t)j * 3); atomicAdd(q, g.x * c.x); atomicAdd(q + 1, g.y * c.y); atomicAdd(q + 2, g.z * c.z); }
         }
+    }
+}
+
+// L[rows[i]] += throughput[i] * (coef[i] * radiance[e[i]] + cst[i]), NaN -> 0 (trace_indirect's `dL[dL.isnan()] = 0`, :454-456,:484-486);
+// then optionally throughput[i] *= weight[i] (:462).  rows / throughput / cst / weight may be NULL.
+__global__ void pt_apply_kernel(float* __restrict__ Lacc, const int32_t* __restrict__ rows, float* __restrict__ throughput,
+                                const float* __restrict__ radiance, const int32_t* __restrict__ e, const float* __restrict__ coef,
+                                const float* __restrict__ cst, const float* __restrict__ weight, int64_t N, int nan_to_zero) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        f3 v = cst ? ld3(cst + i * 3) : mk3(0.f, 0.f, 0.f);
+        if (e && e[i] >= 0) { f3 r = ld3(radiance + (int64_t)e[i] * 3), c = ld3(coef + i * 3); v = mk3(v.x + c.x * r.x, v.y + c.y * r.y, v.z + c.z * r.z); }
+        if (throughput) { f3 t = ld3(throughput + i * 3); v = mk3(t.x * v.x, t.y * v.y, t.z * v.z); }
+        if (nan_to_zero) { if (v.x != v.x) v.x = 0.f; if (v.y != v.y) v.y = 0.f; if (v.z != v.z) v.z = 0.f; }
+        float* q = Lacc + (int64_t)(rows ? rows[i] : i) * 3;
+        q[0] += v.x; q[1] += v.y; q[2] += v.z;                     // rows are unique: no atomics needed
+        if (throughput && weight) { f3 t = ld3(throughput + i * 3), w = ld3(weight + i * 3); st3(throughput + i * 3, mk3(t.x * w.x, t.y * w.y, t.z * w.z)); }
     }
 }
 

@@ -235,18 +235,143 @@ def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du,
         s1, s2 = nxt(N), nxt(N, 2)
         coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
         L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
-                                L.ptr(coef1), L.ptr(e1), L.stream()))
+                                L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 1e-6, L.stream()))
         # BRDF sampling + next intersection (:384-391)
         s1b, s2b = nxt(N), nxt(N, 2)
         wi_b = torch.empty(N, 3, device=dev); pdf_b = torch.empty(N, device=dev); w_b = torch.empty(N, 3, device=dev)
         pos_n = torch.empty(N, 3, device=dev); nrm_n = torch.empty(N, 3, device=dev)
         tri_n = torch.empty(N, device=dev, dtype=torch.int64); hit_n = torch.empty(N, device=dev, dtype=torch.bool)
         L.check(lib.iris_pt_brdf_trace(scene.handle, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1b), L.ptr(s2b), N,
-                                       L.ptr(wi_b), L.ptr(pdf_b), L.ptr(w_b), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(tri_n), L.ptr(hit_n), L.stream()))
+                                       L.ptr(wi_b), L.ptr(pdf_b), L.ptr(w_b), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(tri_n), L.ptr(hit_n), 0, 0.0, L.stream()))
         mat_next = material_net(pos_n)
         rough_n = mat_next["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
         # eval_emitter at the sampled hit + MIS (:394-404)
         coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
         L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi_b), L.ptr(tri_n), L.ptr(rough_n), L.ptr(pdf_b), L.ptr(w_b), N,
-                                        L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.stream()))
+                                        L.ptr(coef2), L.ptr(const2), L.ptr(e2), None, 0.0, 1e-6, L.stream()))
     return _PtAccumulate.apply(radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# refine_shading's integrators: multi-bounce indirect light with NEE + BRDF sampling + MIS
+# (utils/path_tracing.py:409-502 trace_indirect) under a deterministic first hit (:50-124 path_tracing_det_diff,
+# :126-212 path_tracing_det_spec).  Each bounce is the same three fused stages as path_tracing_single, with trace_indirect's
+# constants; the material network is the caller's, evaluated between the stages; paths are compacted every bounce.
+# ----------------------------------------------------------------------------------------------------------------------
+def _mat_tensors(mat):
+    return (mat["albedo"].detach().to(torch.float32).reshape(-1, 3).contiguous(), mat["roughness"].detach().to(torch.float32).reshape(-1).contiguous(),
+            mat["metallic"].detach().to(torch.float32).reshape(-1).contiguous())
+
+
+def _draws(uniforms, dev):
+    u = list(uniforms) if uniforms is not None else None
+    if u is None:
+        return lambda *shape: torch.rand(*shape, device=dev)
+    return lambda *shape: L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(*shape)
+
+
+def _lobe_trace(scene, position, normal, wo, mat, s1, s2, lobe, roughness=0.0):
+    """sample a lobe and find the next intersection (one fused launch)"""
+    N, dev = position.shape[0], position.device
+    wi = torch.empty(N, 3, device=dev); pdf = torch.empty(N, device=dev); w = torch.empty(N, 3, device=dev)
+    pos_n = torch.empty(N, 3, device=dev); nrm_n = torch.empty(N, 3, device=dev)
+    tri_n = torch.empty(N, device=dev, dtype=torch.int64); hit = torch.empty(N, device=dev, dtype=torch.bool)
+    a, r, m = mat if mat is not None else (None, None, None)
+    L.check(L.lib().iris_pt_brdf_trace(scene.handle, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(a), L.ptr(r), L.ptr(m), L.ptr(s1), L.ptr(s2), N,
+                                       L.ptr(wi), L.ptr(pdf), L.ptr(w), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(tri_n), L.ptr(hit), int(lobe), float(roughness), L.stream()))
+    return wi, pdf, w, pos_n, nrm_n, tri_n
+
+
+@torch.no_grad()
+def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir_depth, uniforms=None):
+    """indirect illumination: up to indir_depth bounces of emitter sampling + BRDF sampling with power-2 MIS, paths ending at
+    emitters / the diffuse radiance cache (utils/path_tracing.py:409-502).  Returns L Bx3.  uniforms: optional list of the
+    draws in the reference's order, per bounce rand(N), rand(N,2), rand(N), rand(N,2)."""
+    position = L.require_gpu(position, torch.float32, "position").reshape(-1, 3)
+    wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
+    normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
+    B, dev = position.shape[0], position.device
+    lib, nxt = L.lib(), _draws(uniforms, dev)
+    Lacc = torch.zeros(B, 3, device=dev)
+    rows = torch.arange(B, device=dev, dtype=torch.int32)
+    throughput = torch.ones(B, 3, device=dev)
+    radiance = emitter_net.radiance.detach().to(torch.float32).contiguous()
+    mat = None
+    with torch.cuda.device(dev):
+        eh, sh = emitter_net.handle(dev), emitter_net.slf.handle(dev)
+        for depth in range(indir_depth):
+            N = position.shape[0]
+            if N == 0:
+                break
+            if depth == 0:
+                mat = _mat_tensors(material_net(position))
+            a, r, m = mat
+            s1, s2 = nxt(N), nxt(N, 2)
+            coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
+            L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(a), L.ptr(r), L.ptr(m), L.ptr(s1), L.ptr(s2), N,
+                                    L.ptr(coef1), L.ptr(e1), 1e-12, 1e-12, 0.0, L.stream()))
+            L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e1), L.ptr(coef1), None, None, N, 1, L.stream()))
+            s1b, s2b = nxt(N), nxt(N, 2)
+            wi, pdf, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, mat, s1b, s2b, 0)
+            mat_next = _mat_tensors(material_net(pos_n))
+            coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
+            valid_next = torch.empty(N, device=dev, dtype=torch.bool)
+            L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi), L.ptr(tri_n), L.ptr(mat_next[1]), L.ptr(pdf), L.ptr(w), N,
+                                            L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(valid_next), 0.6, 1e-12, L.stream()))
+            L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e2), L.ptr(coef2), L.ptr(const2), L.ptr(w), N, 1, L.stream()))
+            keep = torch.nonzero(valid_next, as_tuple=False).reshape(-1)        # continue only the paths that neither ended nor left the scene
+            rows, throughput = rows[keep].contiguous(), throughput[keep].contiguous()
+            position, wo, normal = pos_n[keep].contiguous(), (-wi[keep]).contiguous(), nrm_n[keep].contiguous()
+            mat = tuple(t[keep].contiguous() for t in mat_next)
+    return Lacc
+
+
+@torch.no_grad()
+def _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, lobe, roughness, uniforms):
+    positions = L.require_gpu(positions, torch.float32, "positions").reshape(-1, 3)
+    wis = L.require_gpu(wis, torch.float32, "wis").reshape(-1, 3)
+    normals = L.require_gpu(normals, torch.float32, "normals").reshape(-1, 3)
+    dev = positions.device
+    sel = torch.nonzero(triangle_idxs != -1, as_tuple=False).reshape(-1)
+    P = sel.numel()
+    if P == 0:
+        return sel, None, None
+    u = list(uniforms) if uniforms is not None else None
+    position = positions[sel].repeat_interleave(spp, 0).contiguous()
+    normal = normals[sel].repeat_interleave(spp, 0).contiguous()
+    wo = (-wis[sel]).repeat_interleave(spp, 0).contiguous()
+    N = P * spp
+    with torch.cuda.device(dev):
+        # (the reference also evaluates the first-hit material here, :77/:157, and never uses it)
+        s2 = L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(N, 2) if u is not None else torch.rand(N, 2, device=dev)
+        wi, _, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, None, None, s2, lobe, roughness)
+        mat_next = material_net(pos_n)
+        Le, _, valid_next = emitter_net.eval_emitter(pos_n, wi, tri_n, mat_next["roughness"])        # default trace_roughness = 0.6
+        keep = torch.nonzero(valid_next, as_tuple=False).reshape(-1)
+        L_indir = trace_indirect(scene, emitter_net, material_net, pos_n[keep], -wi[keep], nrm_n[keep], indir_depth, uniforms=u)
+        total = Le.clone()
+        total[keep] += L_indir                 # both weights multiply (Le + L_indir) of the same path
+    return sel, w, total.reshape(P, spp, 3)
+
+
+def path_tracing_det_diff(scene, emitter_net, material_net, positions, wis, normals, uvs, triangle_idxs, spp, indir_depth, uniforms=None):
+    """diffuse shading with a deterministic first intersection and indir_depth bounces of indirect light
+    (utils/path_tracing.py:50-124).  Returns Lout Bx3 (zeros where triangle_idxs == -1)."""
+    Lout = torch.zeros_like(positions.reshape(-1, 3))
+    sel, w, total = _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, 1, 0.0, uniforms)
+    if total is not None:
+        Lout[sel] = total.mean(1)              # sample_diffuse's brdf_weight is 1 (model/brdf.py:86)
+    return Lout
+
+
+def path_tracing_det_spec(scene, emitter_net, material_net, roughness_level, positions, wis, normals, uvs, triangle_idxs, spp, indir_depth, uniforms=None):
+    """the two Fresnel-split specular shadings at one roughness level (utils/path_tracing.py:126-212).  Returns L0out, L1out."""
+    L0 = torch.zeros_like(positions.reshape(-1, 3)); L1 = torch.zeros_like(L0)
+    r = float(roughness_level.detach().float().cpu().item()) if isinstance(roughness_level, torch.Tensor) else float(roughness_level)
+    sel, w, total = _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, 2, r, uniforms)
+    if total is not None:
+        P, spp_ = total.shape[0], total.shape[1]
+        g = w.reshape(P, spp_, 3)
+        L0[sel] = (g[..., 0:1] * total).mean(1)
+        L1[sel] = (g[..., 1:2] * total).mean(1)
+    return L0, L1

@@ -881,7 +881,8 @@ static inline v3 ff_normal(const orc_scene *sc, const orc_hit *h, v3 d) {
 }
 /* :357-382  term1 = coef1 * radiance[e1] */
 ORC_API void orc_pt_nee(const orc_scene *sc, const orc_emitter *e, const float *pos, const float *nrm, const float *wo, const float *albedo,
-                        const float *rough, const float *metal, const float *s1, const float *s2, int64_t N, float *coef1, int32_t *e1) {
+                        const float *rough, const float *metal, const float *s1, const float *s2, int64_t N, float *coef1, int32_t *e1,
+                        float g_eps, float pdf_eps, float mis_eps) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < N; ++i) {
         const v3 x = v3_ld(pos + i * 3), n = v3_ld(nrm + i * 3), w = v3_ld(wo + i * 3);
@@ -896,17 +897,17 @@ ORC_API void orc_pt_nee(const orc_scene *sc, const orc_emitter *e, const float *
             emit_vis = emit_tri == h.tri;
             ord = e->is_emitter[h.tri] ? e->emitter_idx[h.tri] : -1;
             const v3 dl = v3_sub(ep, x);
-            float d2 = (dl.x * dl.x + dl.y * dl.y) + dl.z * dl.z; if (d2 < 1e-6f) d2 = 1e-6f;
+            float d2 = (dl.x * dl.x + dl.y * dl.y) + dl.z * dl.z; if (d2 < g_eps) d2 = g_eps;
             G = fabsf(t_dot(v3_make(-wi.x, -wi.y, -wi.z), en)) / d2;
         }
         v3 brdf; float brdf_pdf;
         eval_brdf1(wi, w, n, mat_at(albedo, rough, metal, i), &brdf, &brdf_pdf);
         brdf_pdf = brdf_pdf * G;
         float w_mis = 0.f;
-        if (emit_pdf > 0.f && !isinf(brdf_pdf)) { float den = emit_pdf * emit_pdf + brdf_pdf * brdf_pdf; if (den < 1e-6f) den = 1e-6f; w_mis = emit_pdf * emit_pdf / den; }
+        if (emit_pdf > 0.f && !isinf(brdf_pdf)) { float den = emit_pdf * emit_pdf + brdf_pdf * brdf_pdf; if (mis_eps > 0.f && den < mis_eps) den = mis_eps; w_mis = emit_pdf * emit_pdf / den; }
         if (isinf(emit_pdf) || brdf_pdf == 0.f) w_mis = 1.f;
         const float sv = emit_vis ? 1.f : 0.f;
-        const float ew = G / (emit_pdf < 1e-6f ? 1e-6f : emit_pdf);
+        const float ew = G / (emit_pdf < pdf_eps ? pdf_eps : emit_pdf);
         v3_st(coef1 + i * 3, v3_make(brdf.x * (sv * ew) * w_mis, brdf.y * (sv * ew) * w_mis, brdf.z * (sv * ew) * w_mis));
         e1[i] = (emit_valid && ord >= 0) ? (int32_t)ord : -1;
     }
@@ -914,12 +915,14 @@ ORC_API void orc_pt_nee(const orc_scene *sc, const orc_emitter *e, const float *
 /* :384-391 */
 ORC_API void orc_pt_brdf_trace(const orc_scene *sc, const float *pos, const float *nrm, const float *wo, const float *albedo, const float *rough,
                                const float *metal, const float *s1, const float *s2, int64_t N, float *wi_out, float *pdf_out, float *w_out,
-                               float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid) {
+                               float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid, int lobe, float lobe_rough) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < N; ++i) {
         const v3 x = v3_ld(pos + i * 3), n = v3_ld(nrm + i * 3), w = v3_ld(wo + i * 3);
         v3 wi, bw; float pdf;
-        sample_brdf1(s1[i], s2[i * 2], s2[i * 2 + 1], w, n, mat_at(albedo, rough, metal, i), &wi, &pdf, &bw);
+        if (lobe == 0) sample_brdf1(s1[i], s2[i * 2], s2[i * 2 + 1], w, n, mat_at(albedo, rough, metal, i), &wi, &pdf, &bw);
+        else if (lobe == 1) { wi = diffuse_sampler(s2[i * 2], s2[i * 2 + 1], n); pdf = relu(t_dot(n, wi)) / PI_F; bw = v3_make(1.f, 1.f, 1.f); }   /* model/brdf.py:78-88 */
+        else { spec_sample r = sample_specular1(s2[i * 2], s2[i * 2 + 1], w, n, lobe_rough); wi = r.wi; pdf = r.pdf; bw = v3_make(r.g0, r.g1, 0.f); }  /* :112-136 */
         const v3 o = v3_make(x.x + RAY_EPS * wi.x, x.y + RAY_EPS * wi.y, x.z + RAY_EPS * wi.z);
         orc_hit h = intersect_bvh(sc, o, wi, NULL, NULL);
         v3 pn = v3_make(0, 0, 0), nn = v3_make(0, 0, 0);
@@ -931,7 +934,7 @@ ORC_API void orc_pt_brdf_trace(const orc_scene *sc, const float *pos, const floa
 /* :394-404  term2 = coef2 * radiance[e2] + const2 */
 ORC_API void orc_pt_brdf_finish(const orc_emitter *e, const orc_slf *slf, const float *pos, const float *pos_next, const float *nrm_next, const float *wi_in,
                                 const int64_t *tri_next, const float *rough_next, const float *pdf_in, const float *w_in, int64_t N, float *coef2,
-                                float *const2, int32_t *e2) {
+                                float *const2, int32_t *e2, uint8_t *valid_next_out, float trace_rough, float g_eps) {
     for (int64_t i = 0; i < N; ++i) {
         const v3 x = v3_ld(pos + i * 3), pn = v3_ld(pos_next + i * 3), nn = v3_ld(nrm_next + i * 3), wi = v3_ld(wi_in + i * 3);
         const int64_t tri = tri_next[i];
@@ -942,11 +945,12 @@ ORC_API void orc_pt_brdf_finish(const orc_emitter *e, const orc_slf *slf, const 
         if (is_area) { float a = e->area[ord]; if (a < 1e-12f) a = 1e-12f; emit_pdf = e->emitter_pdf / a; }
         int valid_next = (!is_area) && vis;
         v3 sl = v3_make(0, 0, 0);
-        if ((!is_area) && vis && rough_next[i] > 0.0f) { sl = slf_forward(slf, pn); if ((sl.x + sl.y) + sl.z > 0.f) valid_next = 0; }
+        if ((!is_area) && vis && rough_next[i] > trace_rough) { sl = slf_forward(slf, pn); if ((sl.x + sl.y) + sl.z > 0.f) valid_next = 0; }
         const v3 dl = v3_sub(x, pn);
-        float d2 = (dl.x * dl.x + dl.y * dl.y) + dl.z * dl.z; if (d2 < 1e-6f) d2 = 1e-6f;
+        float d2 = (dl.x * dl.x + dl.y * dl.y) + dl.z * dl.z; if (d2 < g_eps) d2 = g_eps;
         float G = fabsf(t_dot(v3_make(-nn.x, -nn.y, -nn.z), wi)) / d2;
         if (!valid_next) G = 1.f;
+        if (valid_next_out) valid_next_out[i] = (uint8_t)valid_next;
         const float brdf_pdf = pdf_in[i] * G;
         float w_mis = 0.f;
         if (brdf_pdf > 0.f && !isinf(emit_pdf)) w_mis = brdf_pdf * brdf_pdf / (emit_pdf * emit_pdf + brdf_pdf * brdf_pdf);

@@ -279,15 +279,16 @@ def path_tracing_single(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_d
     a, r, m = _mat(material_fn(pos))
     s1, s2, s1b, s2b = u[1].reshape(-1), u[2].reshape(-1, 2), u[3].reshape(-1), u[4].reshape(-1, 2)
     coef1 = np.empty((N, 3), np.float32); e1 = np.empty(N, np.int32)
-    lib().orc_pt_nee(scene.h, emitter.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(coef1), _p(e1))
+    lib().orc_pt_nee(scene.h, emitter.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(coef1), _p(e1),
+                     C.c_float(1e-6), C.c_float(1e-6), C.c_float(1e-6))
     wi_b = np.empty((N, 3), np.float32); pdf_b = np.empty(N, np.float32); w_b = np.empty((N, 3), np.float32)
     pos_n = np.empty((N, 3), np.float32); nrm_n = np.empty((N, 3), np.float32); tri_n = np.empty(N, np.int64); hit_n = np.empty(N, np.uint8)
     lib().orc_pt_brdf_trace(scene.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1b), _p(s2b), C.c_int64(N), _p(wi_b), _p(pdf_b), _p(w_b),
-                            _p(pos_n), _p(nrm_n), _p(tri_n), _p(hit_n))
+                            _p(pos_n), _p(nrm_n), _p(tri_n), _p(hit_n), C.c_int(0), C.c_float(0.0))
     _, r_n, _ = _mat(material_fn(pos_n))
     coef2 = np.empty((N, 3), np.float32); const2 = np.empty((N, 3), np.float32); e2 = np.empty(N, np.int32)
     lib().orc_pt_brdf_finish(emitter.h, emitter.slf.h, _p(pos), _p(pos_n), _p(nrm_n), _p(wi_b), _p(tri_n), _p(r_n), _p(pdf_b), _p(w_b), C.c_int64(N),
-                             _p(coef2), _p(const2), _p(e2))
+                             _p(coef2), _p(const2), _p(e2), None, C.c_float(0.0), C.c_float(1e-6))
     Lout = np.empty((B, 3), np.float32)
     lib().orc_pt_accumulate(_p(rad), _p(e0), _p(path_of), _p(e1), _p(coef1), _p(e2), _p(coef2), _p(const2), C.c_int64(B), C.c_int(spp), _p(Lout))
     terms = {"e0": e0, "path_of": path_of, "e1": e1, "coef1": coef1, "e2": e2, "coef2": coef2, "const2": const2, "B": B, "spp": spp,
@@ -308,3 +309,81 @@ def grad_radiance(terms, gL, n_rad):
         mm = e[j] >= 0
         np.add.at(g, e[j][mm], gp[act][mm] * c[j][mm].astype(np.float64))
     return g.astype(np.float32)
+
+
+# ---------------------------------------------------------------- refine_shading integrators
+def _lobe_trace(scene, pos, nrm, wo, mat, s1, s2, lobe, rough=0.0):
+    N = pos.shape[0]
+    wi = np.empty((N, 3), np.float32); pdf = np.empty(N, np.float32); w = np.empty((N, 3), np.float32)
+    pos_n = np.empty((N, 3), np.float32); nrm_n = np.empty((N, 3), np.float32); tri_n = np.empty(N, np.int64); hit = np.empty(N, np.uint8)
+    a, r, m = mat if mat is not None else (None, None, None)
+    lib().orc_pt_brdf_trace(scene.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(wi), _p(pdf), _p(w),
+                            _p(pos_n), _p(nrm_n), _p(tri_n), _p(hit), C.c_int(lobe), C.c_float(np.float32(rough)))
+    return wi, pdf, w, pos_n, nrm_n, tri_n
+
+
+def _apply(Lacc, rows, throughput, radiance, e, coef, cst, weight):
+    """the HIP pt_apply kernel in numpy f32, same operation order"""
+    v = np.zeros_like(coef) if cst is None else cst.copy()
+    m = e >= 0
+    v[m] = v[m] + coef[m] * radiance[e[m]]
+    v = throughput * v
+    v[np.isnan(v)] = 0
+    Lacc[rows] += v
+    if weight is not None:
+        throughput *= weight
+
+
+def trace_indirect(scene, emitter, material_fn, position, wo, normal, indir_depth, uniforms):
+    """utils/path_tracing.py:409-502"""
+    position = _f32(position); wo = _f32(wo); normal = _f32(normal); B = position.shape[0]
+    u = [np.ascontiguousarray(np.asarray(x, np.float32)) for x in uniforms]
+    Lacc = np.zeros((B, 3), np.float32); rows = np.arange(B); thr = np.ones((B, 3), np.float32)
+    rad = emitter.radiance
+    mat = None
+    for depth in range(indir_depth):
+        N = position.shape[0]
+        if N == 0:
+            break
+        if depth == 0:
+            mat = _mat(material_fn(position))
+        a, r, m = mat
+        s1, s2 = u.pop(0).reshape(-1), u.pop(0).reshape(-1, 2)
+        coef1 = np.empty((N, 3), np.float32); e1 = np.empty(N, np.int32)
+        lib().orc_pt_nee(scene.h, emitter.h, _p(position), _p(normal), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(coef1), _p(e1),
+                         C.c_float(1e-12), C.c_float(1e-12), C.c_float(0.0))
+        _apply(Lacc, rows, thr, rad, e1, coef1, None, None)
+        s1b, s2b = u.pop(0).reshape(-1), u.pop(0).reshape(-1, 2)
+        wi, pdf, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, mat, s1b, s2b, 0)
+        mat_next = _mat(material_fn(pos_n))
+        coef2 = np.empty((N, 3), np.float32); const2 = np.empty((N, 3), np.float32); e2 = np.empty(N, np.int32); vn = np.empty(N, np.uint8)
+        lib().orc_pt_brdf_finish(emitter.h, emitter.slf.h, _p(position), _p(pos_n), _p(nrm_n), _p(wi), _p(tri_n), _p(mat_next[1]), _p(pdf), _p(w), C.c_int64(N),
+                                 _p(coef2), _p(const2), _p(e2), _p(vn), C.c_float(0.6), C.c_float(1e-12))
+        _apply(Lacc, rows, thr, rad, e2, coef2, const2, w)
+        keep = vn.astype(bool)
+        rows, thr = rows[keep], np.ascontiguousarray(thr[keep])
+        position, wo, normal = _f32(pos_n[keep]), _f32(-wi[keep]), _f32(nrm_n[keep])
+        mat = tuple(np.ascontiguousarray(t[keep]) for t in mat_next)
+    return Lacc
+
+
+def path_tracing_det(scene, emitter, material_fn, positions, wis, normals, triangle_idxs, spp, indir_depth, uniforms, roughness=None):
+    """utils/path_tracing.py:50-124 (roughness None -> diffuse) and :126-212 (specular).  Returns Lout or (L0out, L1out)."""
+    positions = _f32(positions); wis = _f32(wis); normals = _f32(normals)
+    u = [np.ascontiguousarray(np.asarray(x, np.float32)) for x in uniforms]
+    sel = np.nonzero(np.asarray(triangle_idxs) != -1)[0]; P = len(sel)
+    outs = [np.zeros_like(positions) for _ in range(1 if roughness is None else 2)]
+    if P:
+        position = _f32(np.repeat(positions[sel], spp, 0)); normal = _f32(np.repeat(normals[sel], spp, 0)); wo = _f32(np.repeat(-wis[sel], spp, 0))
+        s2 = u.pop(0).reshape(-1, 2)
+        wi, _, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, None, None, s2, 1 if roughness is None else 2, 0.0 if roughness is None else roughness)
+        mat_next = material_fn(pos_n)
+        Le, _, vn = emitter.eval_emitter(pos_n, tri_n, mat_next["roughness"], 0.6)
+        total = Le.copy()
+        total[vn] += trace_indirect(scene, emitter, material_fn, pos_n[vn], -wi[vn], nrm_n[vn], indir_depth, u)
+        if roughness is None:
+            outs[0][sel] = total.reshape(P, spp, 3).mean(1, dtype=np.float64).astype(np.float32)
+        else:
+            for k in range(2):
+                outs[k][sel] = (w[:, k:k + 1] * total).reshape(P, spp, 3).mean(1, dtype=np.float64).astype(np.float32)
+    return outs[0] if roughness is None else tuple(outs)

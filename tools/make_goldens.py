@@ -78,6 +78,7 @@ def surface_mask(verts, faces, H, vmin, vmax, n_per_edge=96):
 
 def main():
     import torch
+    import torch.nn.functional as NF
     _stub_modules()
     sys.path.insert(0, REF)
     os.chdir(REF)
@@ -359,6 +360,39 @@ def main():
              L=Lp.detach().numpy(), grad_weight=wgt.numpy(), grad_radiance=gr.numpy(), emitter_vertices=bev_real.numpy(),
              emitter_cdf=em_l.emitter_cdf.numpy(), radiance=em_l.radiance.detach().numpy())
     print("pt_single: L mean", float(Lp.mean()), "grad nnz rows", int((gr.abs().sum(-1) > 0).sum()), "draws", [tuple(r.shape) for r in recorded])
+
+    # ------------------------------------------------------------------ 8(f)-1: refine_shading integrators (multi-bounce, no grad)
+    def record(fn):
+        rec = []
+
+        def rr(*a, **k):
+            k.pop("device", None)
+            t = real_rand(*a, **k); rec.append(t.clone()); return t
+        torch.rand = rr
+        try:
+            out = fn()
+        finally:
+            torch.rand = real_rand
+        return out, rec
+    ref_mat = RefStub()
+    with torch.no_grad():
+        ppos, pnrm, puv, ptri, pvalid = rpt.ray_intersect(None, ro, NF.normalize(rd, dim=-1))
+        rdn = NF.normalize(rd, dim=-1)
+        torch.manual_seed(3)
+        Li, rec_i = record(lambda: rpt.trace_indirect(None, em_l, ref_mat, ppos[pvalid], -rdn[pvalid], pnrm[pvalid], 3))
+        torch.manual_seed(4)
+        Ld, rec_d = record(lambda: rpt.path_tracing_det_diff(None, em_l, ref_mat, ppos, rdn, pnrm, puv, ptri, 4, 3))
+        torch.manual_seed(5)
+        (Ls0, Ls1), rec_s = record(lambda: rpt.path_tracing_det_spec(None, em_l, ref_mat, torch.tensor(0.412), ppos, rdn, pnrm, puv, ptri, 4, 3))
+    ref = {"rays_o": ro.numpy(), "rays_d": rdn.numpy(), "position": ppos.numpy(), "normal": pnrm.numpy(), "triangle_idx": ptri.numpy(), "valid": pvalid.numpy(),
+           "L_indirect": Li.numpy(), "L_det_diff": Ld.numpy(), "L_det_spec0": Ls0.numpy(), "L_det_spec1": Ls1.numpy(),
+           "n_i": len(rec_i), "n_d": len(rec_d), "n_s": len(rec_s)}
+    for tag, rec in (("i", rec_i), ("d", rec_d), ("s", rec_s)):
+        for k, t in enumerate(rec):
+            ref[f"u_{tag}_{k}"] = t.numpy()
+    np.savez(os.path.join(OUT, "refine.npz"), **ref)
+    print("refine: indirect mean", float(Li.mean()), "det_diff mean", float(Ld.mean()), "det_spec means", float(Ls0.mean()), float(Ls1.mean()),
+          "draws", len(rec_i), len(rec_d), len(rec_s))
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
