@@ -187,6 +187,15 @@ IRIS_API int iris_pt_accumulate_fwd(const float *radiance, const int32_t *e0, co
 IRIS_API int iris_pt_accumulate_bwd(const float *gL, const int32_t *e0, const int32_t *path_of, const int32_t *e1, const float *coef1,
                            const int32_t *e2, const float *coef2, int64_t B, int spp, float *g_radiance, iris_stream_t);
 
+/* ---- 8(f)-2: pooling builders of the stages that write vslf.npz / emitter.pth ------------------------------- */
+/* VoxelSLF.scatter_add (model/slf.py:56-61): radiance_acc (kv,3) f32 += rgb, count (kv) int64 += 1 at spatial_idx(x) */
+IRIS_API int iris_slf_scatter_add(const iris_slf *, const float *x, const float *rgb, int64_t B, float *radiance_acc, int64_t *count,
+                         iris_stream_t);
+/* occupancy histogram of slf_bake.py:104-110: hist (H^3) f32, index x + y*H + z*H*H */
+IRIS_API int iris_voxel_histogram(const float *x, int64_t B, double voxel_min, double voxel_max, int H, float *hist, iris_stream_t);
+/* per-triangle sums of extract_emitter_ldr.py:90-95: out (F,3) += values (B,3) at idx (B); count (F) f32 nullable */
+IRIS_API int iris_scatter_add_rows(const float *values, const int64_t *idx, int64_t B, int64_t F, float *out, float *count, iris_stream_t);
+
 /* ---- misc --------------------------------------------------------------------------------------------- */
 /* Philox uniforms exactly as the bake kernels draw them (for tests): u2[i] = U(seed, idx0+i, stream_id). */
 IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream_id, int64_t n, float *u2, iris_stream_t);

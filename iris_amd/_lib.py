@@ -56,6 +56,9 @@ PROTOTYPES = {
     "iris_pt_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "iris_pt_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
     "iris_pt_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
+    "iris_slf_scatter_add": [_P, _P, _P, _I64, _P, _P, _P],
+    "iris_voxel_histogram": [_P, _I64, _D, _D, _I32, _P, _P],
+    "iris_scatter_add_rows": [_P, _P, _I64, _I64, _P, _P, _P],
     "iris_last_error": [],
     "iris_version": [],
 }

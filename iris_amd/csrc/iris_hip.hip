@@ -725,3 +725,55 @@ extern "C" IRIS_API int iris_pt_apply(float* L, const int32_t* rows, float* thro
     LAUNCH1D(pt_apply_kernel, N, stream, L, rows, throughput, radiance, e, coef, cst, weight, N, nan_to_zero);
     return IRIS_OK;
 }
+
+// ======================================================================================================
+// 8(f)-2: G-buffer pooling builders (the stages that produce vslf.npz / emitter.pth)
+// ======================================================================================================
+// VoxelSLF.scatter_add (model/slf.py:56-61): radiance[idx] += rgb, count[idx] += 1 with idx = spatial_idx(x).
+// Samples that fall into an empty voxel (idx = -1) are dropped (torch would raise on the negative index).
+__global__ void slf_scatter_add_kernel(SlfDev s, const float* __restrict__ x, const float* __restrict__ rgb, int64_t B, float* __restrict__ acc,
+                                       unsigned long long* __restrict__ count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = slf_index(s, ld3(x + i * 3));
+        if (j < 0) continue;
+        atomicAdd(acc + (int64_t)j * 3, rgb[i * 3]); atomicAdd(acc + (int64_t)j * 3 + 1, rgb[i * 3 + 1]); atomicAdd(acc + (int64_t)j * 3 + 2, rgb[i * 3 + 2]);
+        atomicAdd(count + j, 1ull);
+    }
+}
+extern "C" IRIS_API int iris_slf_scatter_add(const iris_slf* s, const float* x, const float* rgb, int64_t B, float* radiance_acc, int64_t* count,
+                                    iris_stream_t stream) {
+    if (!s || B < 0 || (B > 0 && (!x || !rgb || !radiance_acc || !count))) return fail(IRIS_ERR_ARG, "iris_slf_scatter_add: bad arguments");
+    if (B == 0) return IRIS_OK;
+    LAUNCH1D(slf_scatter_add_kernel, B, stream, s->dev, x, rgb, B, radiance_acc, (unsigned long long*)count);
+    return IRIS_OK;
+}
+// slf_bake.py:104-110: occupancy histogram of the voxel grid, hist[x + y*H + z*H*H] += 1 (float counts, exact below 2^24)
+__global__ void voxel_histogram_kernel(const float* __restrict__ x, int64_t B, float vmin, float den, int H, float* __restrict__ hist) {
+    SlfDev s{}; s.H = H; s.vmin = vmin; s.den = den;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cx = voxel_coord(x[i * 3], s), cy = voxel_coord(x[i * 3 + 1], s), cz = voxel_coord(x[i * 3 + 2], s);
+        atomicAdd(hist + ((int64_t)cz * H + cy) * H + cx, 1.0f);
+    }
+}
+extern "C" IRIS_API int iris_voxel_histogram(const float* x, int64_t B, double voxel_min, double voxel_max, int H, float* hist, iris_stream_t stream) {
+    if (B < 0 || H <= 0 || (B > 0 && (!x || !hist))) return fail(IRIS_ERR_ARG, "iris_voxel_histogram: bad arguments");
+    if (B == 0) return IRIS_OK;
+    LAUNCH1D(voxel_histogram_kernel, B, stream, x, B, (float)voxel_min, (float)(voxel_max - voxel_min), H, hist);
+    return IRIS_OK;
+}
+// extract_emitter_ldr.py:90-95 (torch_scatter.scatter(..., reduce='sum')): out[idx[i]] += values[i], count[idx[i]] += 1; idx < 0 skipped
+__global__ void scatter_add_rows_kernel(const float* __restrict__ values, const int64_t* __restrict__ idx, int64_t B, int64_t F, float* __restrict__ out,
+                                        float* __restrict__ count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = idx[i];
+        if (j < 0 || j >= F) continue;
+        atomicAdd(out + j * 3, values[i * 3]); atomicAdd(out + j * 3 + 1, values[i * 3 + 1]); atomicAdd(out + j * 3 + 2, values[i * 3 + 2]);
+        if (count) atomicAdd(count + j, 1.0f);
+    }
+}
+extern "C" IRIS_API int iris_scatter_add_rows(const float* values, const int64_t* idx, int64_t B, int64_t F, float* out, float* count, iris_stream_t stream) {
+    if (B < 0 || F < 0 || (B > 0 && (!values || !idx || !out))) return fail(IRIS_ERR_ARG, "iris_scatter_add_rows: bad arguments");
+    if (B == 0) return IRIS_OK;
+    LAUNCH1D(scatter_add_rows_kernel, B, stream, values, idx, B, F, out, count);
+    return IRIS_OK;
+}

@@ -58,6 +58,9 @@ class VoxelSLF(nn.Module):
 
     # -- reference API ---------------------------------------------------------------------------------
     def _lookup(self, x, want_idx, want_rgb):
+        if getattr(self, "_stale_radiance", False):     # scatter_add changed the buffers since the tables were uploaded
+            self._stale_radiance = False
+            self.refresh()
         x = L.require_gpu(x, torch.float32, "x").reshape(-1, 3)
         B = x.shape[0]
         idx = torch.empty(B, device=x.device, dtype=torch.int64) if want_idx else None
@@ -73,3 +76,15 @@ class VoxelSLF(nn.Module):
     def forward(self, x):
         """query surface light field; zero radiance in empty space (model/slf.py:63-70)"""
         return {"rgb": self._lookup(x, False, True)[1]}
+
+    def scatter_add(self, x, radiance):
+        """scatter add radiance into the voxel grid and count the entries (model/slf.py:56-61); the caller divides by
+        count afterwards for mean pooling (slf_bake.py:138).  x, radiance: Bx3 on the GPU; the module's `radiance` / `count`
+        buffers must live on the same device."""
+        x = L.require_gpu(x, torch.float32, "x").reshape(-1, 3)
+        radiance = L.require_gpu(radiance, torch.float32, "radiance").reshape(-1, 3)
+        acc = L.require_gpu(self.radiance, torch.float32, "VoxelSLF.radiance buffer")
+        cnt = L.require_gpu(self.count, torch.int64, "VoxelSLF.count buffer")
+        with torch.cuda.device(x.device):
+            L.check(L.lib().iris_slf_scatter_add(self.handle(x.device), L.ptr(x), L.ptr(radiance), x.shape[0], L.ptr(acc), L.ptr(cnt), L.stream()))
+        self._stale_radiance = True           # the handle's radiance copy is refreshed lazily by refresh()

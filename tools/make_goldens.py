@@ -394,6 +394,19 @@ def main():
     print("refine: indirect mean", float(Li.mean()), "det_diff mean", float(Ld.mean()), "det_spec means", float(Ls0.mean()), float(Ls1.mean()),
           "draws", len(rec_i), len(rec_d), len(rec_s))
 
+    # ------------------------------------------------------------------ 8(f)-2: VoxelSLF.scatter_add (mean-pooling builder of slf_bake.py:120-138)
+    torch.manual_seed(6)
+    Hq = 16
+    maskq = torch.rand(Hq, Hq, Hq) < 0.5
+    vq = VoxelSLF(maskq, -0.3, 2.9)
+    kk, jj, ii = torch.where(maskq)
+    pick = torch.randint(0, len(ii), (20000,))
+    cen = (torch.stack([ii, jj, kk], -1)[pick].float() + torch.rand(20000, 3) * 0.98 + 0.01) / Hq * (2.9 + 0.3) - 0.3     # inside occupied voxels
+    radq = torch.rand(20000, 3) * 3
+    vq.scatter_add(cen, radq)
+    np.savez(os.path.join(OUT, "slf_scatter.npz"), mask=maskq.numpy(), voxel_min=-0.3, voxel_max=2.9, x=cen.numpy(), rgb=radq.numpy(),
+             radiance=vq.radiance.numpy(), count=vq.count.numpy())
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
