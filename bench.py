@@ -183,8 +183,18 @@ def main():
         # per-pixel traffic amortised over spp: pos+nrm+wo 36 B + pix_id 4 B in, 24 B out
         bytes_per_ray = n_node * info["node_bytes"] + n_tri * info["tri_bytes"] + (4 + 16 + 4 + info["tri_bytes"]) + (36 + 4 + 24) / spp
         achieved = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
+        # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 --pmc result
+        # for the same kernel / workload is reported when the configuration matches (see profiles/traffic_r1.json)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "traffic_r1.json")))
+            if args.variant in (0, 2) and abs(tj["rays_per_launch"] - rays_per_launch) < 0.01 * rays_per_launch and info["node_bytes"] == 64:
+                traffic = float(tj["traffic_bytes"])
+        except Exception:
+            traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                              "traffic_note": "bytes per launch (r=1.0 lobe), rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, profiles/traffic_r1.json" if traffic else None,
                               "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
                               "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3), "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
                               "mean_over_max_ray_length_in_wave": round((st[1] + st[2]) / max(st[8], 1), 3),

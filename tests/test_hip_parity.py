@@ -447,3 +447,27 @@ def test_bake_view_layout(dev, room_setup):
     assert out["diffuse"].shape == (H * W, 3) and len(out["specular0"]) == 6 and len(out["specular1"]) == 6
     assert out["rays"] == out["n_valid"] * 16 * 7
     assert all(torch.isfinite(t).all() for t in [out["diffuse"]] + out["specular0"] + out["specular1"])
+
+
+def test_bake_edge_cases(dev, room_setup):
+    """empty pixel list, a single pixel, spp above the tile kernel's 8192-ray limit (falls back to the pixel-per-wave kernel),
+    default pix_id, and the workspace contract."""
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    pos, nrm, wo = T(s["pos"][:3], dev), T(s["nrm"][:3], dev), T(s["wo"][:3], dev)
+    e = bs.bake_diffuse(s["sc"], s["em"], pos[:0], nrm[:0], 16)
+    assert e.shape == (0, 3)
+    one = bs.bake_diffuse(s["sc"], s["em"], pos[:1], nrm[:1], 64, seed=4)
+    three = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 64, seed=4)
+    assert torch.equal(one[0], three[0])                       # default pix_id = position in the list
+    assert int(L.lib().iris_bake_workspace_bytes(3, 9000, 0)) == 0
+    big = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 9000, seed=4)          # AUTO -> pixel-per-wave kernel
+    big1 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 9000, seed=4, variant=L.BAKE_PIXEL_PER_WAVE)
+    assert torch.equal(big, big1) and torch.isfinite(big).all()
+    with pytest.raises(L.IrisError):
+        bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 9000, seed=4, variant=L.BAKE_TILE_SORTED)
+    with pytest.raises(L.IrisError):
+        bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 16, u2=torch.rand(5, 2, device=dev))     # wrong number of uniforms
+    a, b = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, torch.tensor(1.0), 8192, seed=1)  # largest tile-kernel spp, 0-d tensor roughness
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""BASELINE cfg 5: path_tracing_single forward + backward throughput (8192 rays x spp 32, 4 calls per step as the reference's
+training_step does with SPP=128, train_emitter.py:181-189) on the synthetic 1 M-triangle room, stub material.
+Prints one JSON line (paths/s = camera paths traced, shaded and back-propagated per second)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+
+
+class GpuStub(torch.nn.Module):
+    """closed-form stand-in for NGPBRDF, evaluated on the GPU"""
+    def forward(self, x):
+        k = torch.tensor([1.3, 2.1, 0.7], device=x.device); ph = torch.tensor([0.1, 0.5, 0.9], device=x.device)
+        return {"albedo": 0.5 + 0.4 * torch.sin(x * k + ph), "roughness": 0.35 + 0.3 * torch.sin(x[:, :1] * 1.7 + x[:, 1:2] * 0.9),
+                "metallic": 0.5 + 0.5 * torch.sin(x[:, 2:3] * 2.3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=8192); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--calls", type=int, default=4)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    args = ap.parse_args()
+    import bench
+    from iris_amd.model.emitter import SLFEmitterLearn
+    from iris_amd.utils.path_tracing import path_tracing_single, Scene
+    from iris_amd.utils.dataset import real_ldr
+    from tools import synth
+    dev = torch.device("cuda:0")
+    ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
+    room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    ep, sp = os.path.join(tmp, "emitter.pth"), os.path.join(tmp, "vslf.npz")
+    torch.save({"is_emitter": torch.from_numpy(emi["is_emitter"]), "emitter_vertices": torch.from_numpy(emi["emitter_vertices"]),
+                "emitter_area": torch.from_numpy(emi["emitter_area"]), "emitter_normal": torch.zeros(len(emi["emitter_area"]), 3),
+                "emitter_radiance": torch.from_numpy(emi["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(slf["mask"]), "voxel_min": slf["voxel_min"], "voxel_max": slf["voxel_max"], "weight": emitter0.slf.state_dict()}, sp)
+    em = SLFEmitterLearn(ep, sp).to(dev)
+    H, W = 1080, 1920
+    K, c2w = synth.camera(H, W, 0)
+    o, d, dx, dy = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, True, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    pick = torch.randint(0, H * W, (args.rays,), generator=g).to(dev)
+    o, d, dx, dy = o[pick], d[pick], dx[pick], dy[pick]
+    mat = GpuStub()
+    target = torch.rand(args.rays, 3, device=dev)
+
+    def step():
+        em.radiance.grad = None
+        loss = 0
+        for _ in range(args.calls):
+            L = path_tracing_single(scene, em, mat, o, d, dx, dy, args.spp)
+            loss = loss + ((L - target) ** 2).mean()
+        loss.backward()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    paths = args.steps * args.calls * args.rays * args.spp
+    print(json.dumps({"metric": "path_tracing_single fwd+bwd", "value": round(paths / dt / 1e6, 2), "unit": "Mpaths/s", "ms_per_step": round(dt / args.steps * 1e3, 2),
+                      "config": {"rays": args.rays, "spp": args.spp, "calls_per_step": args.calls, "triangles": int(room["faces"].shape[0]), "material": "closed-form stub (NGPBRDF is third party)"},
+                      "grad_nonzero_rows": int((em.radiance.grad.abs().sum(-1) > 0).sum())}))
+
+
+if __name__ == "__main__":
+    main()
