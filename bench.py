@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pixel-block", type=int, default=8, help="order valid pixels in BxB image blocks (0 = row-major)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over")
+    ap.add_argument("--emulate-world", type=int, default=0, help="debug: bake only the stripes rank 0 of an N-GPU run would own (no collective), to "
+                    "measure the per-rank time of a strong-scaling run on one GPU; the printed value is then NOT the headline metric")
     ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
     args = ap.parse_args()
 
@@ -96,6 +99,8 @@ def main():
     info = scene.info()
     K, c2w = synth.camera(H, W, 0)
     pix_local = sh.local_pixel_ids(H, W, world, rank, device=dev)
+    if args.emulate_world > 1 and world == 1:
+        pix_local = sh.local_pixel_ids(H, W, args.emulate_world, 0, device=dev)
     rough = bs.roughness_levels().tolist()
     n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
 
@@ -108,23 +113,29 @@ def main():
         g = bs.primary_hits(scene, xs, ds, pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
         P = g["position"].shape[0]
         maps = torch.zeros(n_maps, pix_local.numel(), 3, device=dev)
-        m = 0
         rays = 0
-        if 0 in lobes:
-            maps[m, g["sel"]] = bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant); m += 1
-            rays += P * spp
+        ls = bs.LobeStreams(dev, 1 if record_events else args.streams)     # the timing pass serialises the launches
+        pending = []
         for l in lobes:
             if l == 0:
-                continue
-            if record_events:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()      # torch's current stream == the stream the kernel is launched on (L.stream())
-            a, b = bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"], variant=args.variant)
-            if record_events:
-                e1.record(); ev_pairs.append((e0, e1, P * spp))
-            maps[m, g["sel"]] = a; maps[m + 1, g["sel"]] = b; m += 2
+                pending.append((l, ls.run(lambda: bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant))))
+            else:
+                if record_events:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()      # torch's current stream == the stream the kernel is launched on (L.stream())
+                pending.append((l, ls.run(lambda l=l: bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l,
+                                                                        pix_id=g["pix_id"], variant=args.variant))))
+                if record_events:
+                    e1.record(); ev_pairs.append((e0, e1, P * spp))
             rays += P * spp
-        full = sh.gather_maps(maps, H, W, world, rank)
+        ls.join()
+        m = 0
+        for l, res in pending:
+            if l == 0:
+                maps[m, g["sel"]] = res; m += 1
+            else:
+                maps[m, g["sel"]] = res[0]; maps[m + 1, g["sel"]] = res[1]; m += 2
+        full = maps if (args.emulate_world > 1 and world == 1) else sh.gather_maps(maps, H, W, world, rank)
         return rays, full
 
     def sync():
@@ -139,10 +150,14 @@ def main():
     t0 = time.perf_counter()
     rays_local = 0
     for _ in range(args.steps):
-        r, full = step(record_events=True)
+        r, full = step()
         rays_local += r
     sync()
     dt = time.perf_counter() - t0
+    if rank == 0 and not args.no_roofline and any(l > 0 for l in lobes):
+        for _ in range(2):                      # per-launch durations of the dominant kernel: separate, serialised pass (HIP events
+            step(record_events=True)            # on the launch stream); the timed region above overlaps launches on several streams
+        torch.cuda.synchronize()
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     rays_t = torch.tensor([rays_local], device=dev, dtype=torch.float64)
     if world > 1:

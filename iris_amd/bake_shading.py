@@ -84,6 +84,30 @@ def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None,
     return (Ls0, Ls1, tri) if want_tri else (Ls0, Ls1)
 
 
+class LobeStreams:
+    """Runs the independent lobe launches of one view round-robin on a few HIP streams, so that the tail of one persistent
+    kernel (its last tiles) overlaps with the head of the next instead of idling the chip; `join()` makes the caller's stream
+    wait for all of them.  With n=1 everything stays on the caller's stream."""
+
+    def __init__(self, device, n=3):
+        self.main = torch.cuda.current_stream(device)
+        self.side = [torch.cuda.Stream(device=device) for _ in range(n)] if n > 1 else []
+        self.k = 0
+
+    def run(self, fn):
+        if not self.side:
+            return fn()
+        st = self.side[self.k % len(self.side)]
+        self.k += 1
+        st.wait_stream(self.main)                 # inputs were produced on the caller's stream
+        with torch.cuda.stream(st):
+            return fn()                           # outputs / workspace are allocated in this stream's pool
+
+    def join(self):
+        for st in self.side:
+            self.main.wait_stream(st)
+
+
 def primary_hits(scene, xs, ds, pixel_ids=None, image_width=None, block=8):
     """bake_shading.py:98-101 / :154-157: primary closest hit + compaction to the valid pixels.
     Returns dict(position, normal, wo, pix_id (int32 image-space pixel index), sel, n_pixels).
@@ -105,7 +129,7 @@ def primary_hits(scene, xs, ds, pixel_ids=None, image_width=None, block=8):
 
 
 def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=None, seed=0, pixel_ids=None, lobes=None,
-              image_width=None):
+              image_width=None, n_streams=3):
     """One view: the primary pass once (the reference repeats it, :98 and :154), then the diffuse lobe and the six
     specular roughness levels.  Returns {'diffuse': (N,3), 'specular0': [6x (N,3)], 'specular1': [...], 'n_valid', 'rays'}
     with N = len(xs) rows in the caller's pixel order (zeros at invalid pixels, bake_shading.py:126-127)."""
@@ -119,15 +143,23 @@ def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=Non
         img = torch.zeros(N, 3, device=dev, dtype=torch.float32)
         img[g["sel"]] = v
         return img
+    ls = LobeStreams(dev, n_streams)
+    pending = []
     if lobes is None or 0 in lobes:
-        out["diffuse"] = scatter(bake_diffuse(scene, emitter, g["position"], g["normal"], spp_diffuse, seed=seed, stream_id=0, pix_id=g["pix_id"]))
+        pending.append((0, ls.run(lambda: bake_diffuse(scene, emitter, g["position"], g["normal"], spp_diffuse, seed=seed, stream_id=0, pix_id=g["pix_id"]))))
         out["rays"] += P * spp_diffuse
     for r_idx, rough in enumerate(roughness_levels().tolist()):
         if lobes is not None and (r_idx + 1) not in lobes:
             continue
-        a, b = bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough, spps[r_idx], seed=seed, stream_id=1 + r_idx, pix_id=g["pix_id"])
-        out["specular0"].append(scatter(a)); out["specular1"].append(scatter(b))
+        pending.append((r_idx + 1, ls.run(lambda r_idx=r_idx, rough=rough: bake_specular(
+            scene, emitter, g["position"], g["normal"], g["wo"], rough, spps[r_idx], seed=seed, stream_id=1 + r_idx, pix_id=g["pix_id"]))))
         out["rays"] += P * spps[r_idx]
+    ls.join()
+    for lobe, res in pending:
+        if lobe == 0:
+            out["diffuse"] = scatter(res)
+        else:
+            out["specular0"].append(scatter(res[0])); out["specular1"].append(scatter(res[1]))
     return out
 
 

@@ -551,8 +551,10 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     if (tiled) {
         const int blocks = bake_grid_blocks();
         int tile_px = kTileRays / spp;                       // as many pixels as fit the LDS ray list ...
-        const int64_t even = (P + blocks - 1) / blocks;      // ... but never fewer tiles than workgroups
-        if (even < tile_px) tile_px = (int)even;
+        int tiles_per_block = 4;                             // ... but at least ~4 tiles per workgroup, so that the dynamic tile queue
+        if (const char* e = getenv("IRIS_TILES_PER_BLOCK")) tiles_per_block = std::max(1, atoi(e));   // balances (tuning knob)
+        const int64_t even = (P + (int64_t)blocks * tiles_per_block - 1) / ((int64_t)blocks * tiles_per_block);
+        if (even < tile_px) tile_px = (int)std::max<int64_t>(even, std::min(tile_px, 16));   // not below 16 px: the sort needs rays
         if (tile_px < 1) tile_px = 1;
         a.tile_px = tile_px;
         a.tile_counter = (unsigned int*)workspace;
