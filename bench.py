@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pixel-block", type=int, default=8, help="order valid pixels in BxB image blocks (0 = row-major)")
+    ap.add_argument("--per-lobe", action="store_true", help="one launch per lobe (spread over --streams) instead of the single-launch view kernel")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: bake only the stripes rank 0 of an N-GPU run would own (no collective), to "
                     "measure the per-rank time of a strong-scaling run on one GPU; the printed value is then NOT the headline metric")
@@ -114,9 +115,15 @@ def main():
         P = g["position"].shape[0]
         maps = torch.zeros(n_maps, pix_local.numel(), 3, device=dev)
         rays = 0
-        ls = bs.LobeStreams(dev, 1 if record_events else args.streams)     # the timing pass serialises the launches
         pending = []
-        for l in lobes:
+        if not record_events and args.variant == 0 and not args.per_lobe:
+            # default: the whole view behind ONE persistent launch / one tile queue (iris_bake_view)
+            res = bs.bake_lobes(scene, emitter, g["position"], g["normal"], g["wo"], [None if l == 0 else rough[l - 1] for l in lobes], [spp] * len(lobes),
+                                seed=0, stream_ids=lobes, pix_id=g["pix_id"])
+            pending = list(zip(lobes, res))
+            rays += P * spp * len(lobes)
+        ls = bs.LobeStreams(dev, 1 if record_events else args.streams)     # the timing pass serialises the launches
+        for l in ([] if pending else lobes):
             if l == 0:
                 pending.append((l, ls.run(lambda: bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant))))
             else:

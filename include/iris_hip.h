@@ -133,6 +133,14 @@ IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const 
                        uint32_t stream_id, const int32_t *pix_id, float *Ls0, float *Ls1, int64_t *tri_next,
                        uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes, iris_stream_t);
 
+/* All lobes of one view (bake_shading.py:93-204) in ONE launch with one tile queue: n_lobes <= 8; roughness[l] < 0 selects the
+ * diffuse lobe (out1[l] may be NULL), otherwise the specular lobe of that roughness; spp[l] <= 8192; Philox uniforms only.
+ * roughness / spp / stream_ids / out0 / out1 are HOST arrays.  Outputs are bit-identical to the per-lobe entry points. */
+IRIS_API int iris_bake_view(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm, const float *wo,
+                   const int32_t *pix_id, int64_t P, int n_lobes, const float *roughness, const int32_t *spp,
+                   const uint32_t *stream_ids, uint64_t seed, float *const *out0, float *const *out1, void *workspace,
+                   uint64_t workspace_bytes, iris_stream_t);
+
 /* ---- a10: lerp_specular (utils/ops.py:99-118): specular (B,R,3), roughness (B) -> (B,3) ------------------ */
 IRIS_API int iris_lerp_specular(const float *specular, const float *roughness, int64_t B, int R, float *out, iris_stream_t);
 

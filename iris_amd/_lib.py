@@ -43,6 +43,7 @@ PROTOTYPES = {
     "iris_bake_workspace_bytes": [_I64, _I32, _I32],
     "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _I32, _P, _U64, _P],
     "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
+    "iris_bake_view": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _U64, _P, _P, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
     "iris_sample_emitter": [_P, _P, _P, _P, _I64, _P, _P, _P, _P],

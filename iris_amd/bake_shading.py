@@ -84,6 +84,34 @@ def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None,
     return (Ls0, Ls1, tri) if want_tri else (Ls0, Ls1)
 
 
+def bake_lobes(scene, emitter, position, normal, wo, roughness, spps, seed=0, stream_ids=None, pix_id=None):
+    """All lobes of one view in ONE launch (`iris_bake_view`): roughness[l] is None for the diffuse lobe, a float otherwise.
+    Returns a list with Ld (P,3) for diffuse entries and (Ls0, Ls1) for specular ones -- bit-identical to bake_diffuse /
+    bake_specular with the same stream ids (default: 0 for diffuse, 1 + position in linspace(0.02,1,6) otherwise)."""
+    import ctypes as C
+    position = L.require_gpu(position, torch.float32, "position").reshape(-1, 3)
+    normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
+    wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
+    P, dev, n = position.shape[0], position.device, len(roughness)
+    if pix_id is not None:
+        pix_id = L.require_gpu(pix_id, torch.int32, "pix_id").reshape(-1)
+    levels = roughness_levels().tolist()
+    if stream_ids is None:
+        stream_ids = [0 if r is None else 1 + min(range(N_ROUGHNESS), key=lambda k: abs(levels[k] - float(r))) for r in roughness]
+    outs0 = [torch.empty(P, 3, device=dev, dtype=torch.float32) for _ in range(n)]
+    outs1 = [None if roughness[l] is None else torch.empty(P, 3, device=dev, dtype=torch.float32) for l in range(n)]
+    rough = (C.c_float * n)(*[-1.0 if r is None else float(r) for r in roughness])
+    spp_a = (C.c_int32 * n)(*[int(s) for s in spps])
+    sid = (C.c_uint32 * n)(*[int(s) for s in stream_ids])
+    p0 = (C.c_void_p * n)(*[t.data_ptr() for t in outs0])
+    p1 = (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in outs1])
+    ws, ws_bytes = _workspace(P, 1, True, L.BAKE_AUTO, dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().iris_bake_view(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(pix_id),
+                                       P, n, rough, spp_a, sid, int(seed), p0, p1, L.ptr(ws), ws_bytes, L.stream()))
+    return [outs0[l] if roughness[l] is None else (outs0[l], outs1[l]) for l in range(n)]
+
+
 class LobeStreams:
     """Runs the independent lobe launches of one view round-robin on a few HIP streams, so that the tail of one persistent
     kernel (its last tiles) overlaps with the head of the next instead of idling the chip; `join()` makes the caller's stream
@@ -143,19 +171,26 @@ def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=Non
         img = torch.zeros(N, 3, device=dev, dtype=torch.float32)
         img[g["sel"]] = v
         return img
-    ls = LobeStreams(dev, n_streams)
-    pending = []
-    if lobes is None or 0 in lobes:
-        pending.append((0, ls.run(lambda: bake_diffuse(scene, emitter, g["position"], g["normal"], spp_diffuse, seed=seed, stream_id=0, pix_id=g["pix_id"]))))
-        out["rays"] += P * spp_diffuse
-    for r_idx, rough in enumerate(roughness_levels().tolist()):
-        if lobes is not None and (r_idx + 1) not in lobes:
-            continue
-        pending.append((r_idx + 1, ls.run(lambda r_idx=r_idx, rough=rough: bake_specular(
-            scene, emitter, g["position"], g["normal"], g["wo"], rough, spps[r_idx], seed=seed, stream_id=1 + r_idx, pix_id=g["pix_id"]))))
-        out["rays"] += P * spps[r_idx]
-    ls.join()
+    levels = roughness_levels().tolist()
+    want = [l for l in range(N_ROUGHNESS + 1) if lobes is None or l in lobes]
+    spp_of = lambda l: spp_diffuse if l == 0 else spps[l - 1]
+    if P > 0 and want and all(spp_of(l) <= 8192 for l in want):
+        # one persistent launch for the whole view
+        res = bake_lobes(scene, emitter, g["position"], g["normal"], g["wo"], [None if l == 0 else levels[l - 1] for l in want], [spp_of(l) for l in want],
+                         seed=seed, stream_ids=want, pix_id=g["pix_id"])
+        pending = list(zip(want, res))
+    else:
+        ls = LobeStreams(dev, n_streams)
+        pending = []
+        for l in want:
+            if l == 0:
+                pending.append((0, ls.run(lambda: bake_diffuse(scene, emitter, g["position"], g["normal"], spp_diffuse, seed=seed, stream_id=0, pix_id=g["pix_id"]))))
+            else:
+                pending.append((l, ls.run(lambda l=l: bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], levels[l - 1], spps[l - 1], seed=seed,
+                                                                    stream_id=l, pix_id=g["pix_id"]))))
+        ls.join()
     for lobe, res in pending:
+        out["rays"] += P * spp_of(lobe)
         if lobe == 0:
             out["diffuse"] = scatter(res)
         else:

@@ -293,4 +293,151 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
     flush_stats<COUNT>(a, ts, n_rays);
 }
 
+// ------------------------------------------------------------------------------------------------------- view kernel
+// bake_view_kernel: ALL lobes of a view (diffuse + the specular roughness levels, bake_shading.py:93-204) behind ONE persistent
+// launch and ONE tile queue.  Per tile it is exactly bake_tile_kernel (same phases, same bits); what it removes is the idle
+// time at the end of every per-lobe launch, when the last ~3 ms tiles run on a few CUs -- which matters once a view is sharded
+// over 8 GPUs and a rank has only ~3 tiles per resident workgroup per lobe.
+constexpr int kMaxLobes = 8;
+struct ViewLobe { float rough; int spp; uint32_t stream_id; int spec; int tile_px; int pad_; long long tile_begin; float* out0; float* out1; };
+struct ViewArgs {
+    BakeArgs base;          // scene / tables / pixel tensors / seed / scratch / tile_counter (per-lobe fields unused)
+    int n_lobes;
+    long long n_tiles;      // over all lobes
+    ViewLobe lobe[kMaxLobes];
+};
+
+template <bool SPEC, int LAYOUT, int TILE_STACK>
+__device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk) {
+    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
+    uint32_t* s_hist = s_stack + kTileRays / 4;
+    uint32_t* s_cur = s_hist + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int spp = a.spp;
+    constexpr int NC = SPEC ? 2 : 1;
+    int lpp, ppw, rounds;
+    reduce_geometry(spp, lpp, ppw, rounds);
+    const int sub = lane / lpp, sl = lane - sub * lpp;
+    const float inv_spp = 1.0f / (float)spp;
+    TraceStats ts;
+    uint32_t n_rays = 0;
+    const int64_t p0 = tile * a.tile_px;
+    const int np = (int)min((int64_t)a.tile_px, a.P - p0);
+    const int nr = np * spp;
+    // ---- phase A
+    for (int r = tid; r < nr; r += kBlock) {
+        const int pl = r / spp, s = r - pl * spp;
+        const int64_t p = p0 + pl;
+        const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
+        const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+        f3 t, b;
+        normal_space(n, t, b);
+        float u0, u1;
+        philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+        const f3 wi = SPEC ? specular_sampler(u0, u1, a.rough, w, n, t, b) : diffuse_sampler(u0, u1, n, t, b);
+        const uint32_t key = dir_bin(wi);
+        s_keys[r] = (uint8_t)key;
+        atomicAdd(&s_hist[key], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t c0 = s_hist[lane * 4], c1 = s_hist[lane * 4 + 1], c2 = s_hist[lane * 4 + 2], c3 = s_hist[lane * 4 + 3];
+        uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
+        for (int m = 1; m < 64; m <<= 1) { uint32_t v = __shfl_up(inc, m); if (lane >= m) inc += v; }
+        uint32_t ex = inc - tot;
+        s_cur[lane * 4] = ex; s_cur[lane * 4 + 1] = ex + c0; s_cur[lane * 4 + 2] = ex + c0 + c1; s_cur[lane * 4 + 3] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+    // ---- phase B
+    for (int r = tid; r < nr; r += kBlock) {
+        const uint32_t pos = atomicAdd(&s_cur[s_keys[r]], 1u);
+        s_sorted[pos] = (uint16_t)r;
+    }
+    __syncthreads();
+    // ---- phase C
+    for (;;) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(s_chunk, 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c * 64 >= nr) break;
+        const int i = c * 64 + lane;
+        if (i < nr) {
+            const int r = s_sorted[i];
+            const int pl = r / spp, s = r - pl * spp;
+            const int64_t p = p0 + pl;
+            const f3 x = ld3(a.pos + p * 3), n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
+            const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+            f3 t, b;
+            normal_space(n, t, b);
+            RayOut o = shade_sample<SPEC, false, LAYOUT, TILE_STACK>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
+            float4* q = res + (size_t)r * NC;
+            q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
+            if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+    // ---- phase D
+    const int n_groups = (np + ppw - 1) / ppw;
+    for (int g = wave; g < n_groups; g += kBlock / 64) {
+        const int pl = g * ppw + sub;
+        const bool pvalid = pl < np;
+        float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int rr = 0; rr < rounds; ++rr) {
+            const int s = rr * 64 + sl;
+            if (pvalid && s < spp) {
+                const float4* q = res + (size_t)(pl * spp + s) * NC;
+                const float4 qa = q[0];
+                a0x += qa.x; a0y += qa.y; a0z += qa.z;
+                if (SPEC) { const float4 qb = q[1]; a1x += qa.w; a1y += qb.x; a1z += qb.y; }
+            }
+        }
+        for (int m = 1; m < lpp; m <<= 1) {
+            a0x += __shfl_xor(a0x, m); a0y += __shfl_xor(a0y, m); a0z += __shfl_xor(a0z, m);
+            if (SPEC) { a1x += __shfl_xor(a1x, m); a1y += __shfl_xor(a1y, m); a1z += __shfl_xor(a1z, m); }
+        }
+        if (pvalid && sl == 0) {
+            const int64_t p = p0 + pl;
+            st3(a.out0 + p * 3, mk3(a0x * inv_spp, a0y * inv_spp, a0z * inv_spp));
+            if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
+        }
+    }
+}
+
+// The view kernel needs only 77 VGPRs, which would allow 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B); with 24
+// resident waves per CU that configuration died with a GPU memory access fault on the pool's MI355X (5 waves / 10 entries and
+// 6 waves / 12 entries -- which is LDS-limited to 5 blocks -- both run clean), so it stays at the tile kernel's 5 / 12.
+#ifndef IRIS_VIEW_WAVES
+#define IRIS_VIEW_WAVES 5
+#endif
+#ifndef IRIS_VIEW_STACK
+#define IRIS_VIEW_STACK 12
+#endif
+template <int LAYOUT>
+__global__ __launch_bounds__(kBlock, IRIS_VIEW_WAVES) void bake_view_kernel(ViewArgs v) {
+    constexpr int kTileStack = IRIS_VIEW_STACK;
+    __shared__ uint16_t s_sorted[kTileRays];
+    __shared__ uint32_t s_stack[kTileStack * kBlock];
+    __shared__ int s_tile, s_chunk;
+    static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
+    const int tid = threadIdx.x;
+    float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { s_tile = (int)atomicAdd(v.base.tile_counter, 1u); s_chunk = 0; }
+        (s_stack + kTileRays / 4)[tid] = 0;   // histogram
+        __syncthreads();
+        const long long gt = s_tile;
+        if (gt >= v.n_tiles) break;
+        int l = 0;
+        for (int k = 1; k < v.n_lobes; ++k) if (gt >= v.lobe[k].tile_begin) l = k;   // wave-uniform
+        BakeArgs a = v.base;
+        a.spp = v.lobe[l].spp; a.rough = v.lobe[l].rough; a.stream_id = v.lobe[l].stream_id; a.tile_px = v.lobe[l].tile_px;
+        a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr;
+        if (v.lobe[l].spec) view_tile<true, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk);
+        else view_tile<false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk);
+    }
+}
+
 }  // namespace iris

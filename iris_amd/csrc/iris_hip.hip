@@ -522,6 +522,7 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // a3..a7 fused bake kernels (iris_bake.h)
 // ======================================================================================================
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
+static int view_grid_blocks() { return num_cus() * IRIS_VIEW_WAVES; }
 
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
     if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
@@ -584,6 +585,45 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         const int grid = grid_for(n_groups * 64, kBlock, num_cus() * 6);
         IRIS_LAUNCH_BAKE(bake_kernel, grid);
     }
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+// All lobes of a view in one launch (see bake_view_kernel).  roughness[l] < 0 selects the diffuse lobe.
+extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
+                              const float* wo, const int32_t* pix_id, int64_t P, int n_lobes, const float* roughness, const int32_t* spp,
+                              const uint32_t* stream_ids, uint64_t seed, float* const* out0, float* const* out1, void* workspace,
+                              uint64_t workspace_bytes, iris_stream_t stream) {
+    if (!sc || !em || !slf || P < 0 || n_lobes < 1 || n_lobes > kMaxLobes || !roughness || !spp || !stream_ids || !out0 || !out1 ||
+        (P > 0 && (!pos || !nrm || !wo)))
+        return fail(IRIS_ERR_ARG, "iris_bake_view: bad arguments");
+    if (P == 0) return IRIS_OK;
+    const uint64_t need = iris_bake_workspace_bytes(P, 1, 1);
+    if (!workspace || workspace_bytes < need) return fail(IRIS_ERR_ARG, "iris_bake_view: workspace of iris_bake_workspace_bytes() bytes required");
+    ViewArgs v{};
+    v.base.sc = sc->dev; v.base.em = em->dev; v.base.slf = slf->dev;
+    v.base.pos = pos; v.base.nrm = nrm; v.base.wo = wo; v.base.pix_id = pix_id; v.base.P = P; v.base.seed = seed;
+    v.base.tile_counter = (unsigned int*)workspace;
+    v.base.scratch = (float4*)((char*)workspace + 256);
+    v.n_lobes = n_lobes;
+    const int blocks = view_grid_blocks();
+    long long t = 0;
+    for (int l = 0; l < n_lobes; ++l) {
+        if (spp[l] < 1 || spp[l] > kTileRays) return fail(IRIS_ERR_ARG, "iris_bake_view: spp must be in [1, 8192]");
+        if (!out0[l] || (roughness[l] >= 0.f && !out1[l])) return fail(IRIS_ERR_ARG, "iris_bake_view: null output");
+        int tile_px = kTileRays / spp[l];
+        const int64_t even = (P * n_lobes + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4);   // >= ~4 tiles per workgroup over the whole view
+        if (even < tile_px) tile_px = (int)std::max<int64_t>(even, std::min(tile_px, 16));
+        if (tile_px < 1) tile_px = 1;
+        v.lobe[l].rough = roughness[l]; v.lobe[l].spp = spp[l]; v.lobe[l].stream_id = stream_ids[l]; v.lobe[l].spec = roughness[l] >= 0.f ? 1 : 0;
+        v.lobe[l].tile_px = tile_px; v.lobe[l].tile_begin = t; v.lobe[l].out0 = out0[l]; v.lobe[l].out1 = out1[l];
+        t += (P + tile_px - 1) / tile_px;
+    }
+    v.n_tiles = t;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+    const int grid = (int)std::min<long long>(blocks, t);
+    if (v.base.sc.layout == kLayoutQ8) hipLaunchKernelGGL(bake_view_kernel<kLayoutQ8>, dim3(grid), dim3(kBlock), 0, st, v);
+    else hipLaunchKernelGGL(bake_view_kernel<kLayoutF32>, dim3(grid), dim3(kBlock), 0, st, v);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

@@ -471,3 +471,25 @@ def test_bake_edge_cases(dev, room_setup):
         bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 16, u2=torch.rand(5, 2, device=dev))     # wrong number of uniforms
     a, b = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, torch.tensor(1.0), 8192, seed=1)  # largest tile-kernel spp, 0-d tensor roughness
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
+
+
+def test_view_kernel_equals_per_lobe_launches(dev, room_setup):
+    """iris_bake_view (all lobes of a view behind one launch / one tile queue) gives the bits of the per-lobe entry points,
+    with the reference's per-lobe spp (256 / 64 / 128...) and with a ragged pixel count."""
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    P = 1237
+    pos, nrm, wo = T(s["pos"][:P], dev), T(s["nrm"][:P], dev), T(s["wo"][:P], dev)
+    pix = T((np.arange(P, dtype=np.int32) * 3 + 1), dev)
+    levels = bs.roughness_levels().tolist()
+    rough = [None] + levels
+    spps = [256, 64, 128, 128, 128, 128, 128]
+    res = bs.bake_lobes(s["sc"], s["em"], pos, nrm, wo, rough, spps, seed=9, pix_id=pix)
+    ref = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 256, seed=9, stream_id=0, pix_id=pix)
+    assert torch.equal(res[0], ref)
+    for k in range(6):
+        a, b = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, levels[k], spps[k + 1], seed=9, stream_id=1 + k, pix_id=pix)
+        assert torch.equal(res[k + 1][0], a) and torch.equal(res[k + 1][1], b), k
+    one = bs.bake_lobes(s["sc"], s["em"], pos[:1], nrm[:1], wo[:1], [0.5], [16], seed=1, stream_ids=[4])
+    a, b = bs.bake_specular(s["sc"], s["em"], pos[:1], nrm[:1], wo[:1], 0.5, 16, seed=1, stream_id=4)
+    assert torch.equal(one[0][0], a) and torch.equal(one[0][1], b)
