@@ -217,8 +217,8 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                               "note": "algorithmic bytes are served by L1/L2/Infinity Cache (working set ~160 MB), so achieved/HBM-peak is not a utilisation figure; "
-                                      "the kernel is VALU-issue bound (DESIGN.md section 5); launch_ms is from a serialised pass (--streams 1 behaviour) and agrees with "
-                                      "profiles/r1_final_streams1_kernel_stats.csv",
+                                      "the kernel is VALU-issue bound (DESIGN.md section 5); the timed region runs all lobes in one bake_view_kernel launch, launch_ms / achieved are priced on the per-lobe specular "
+                                      "kernel (same tile code) in a separate serialised pass and agree with profiles/r1_final_kernel_stats.csv",
                               "traffic_note": "bytes per launch (r=1.0 lobe), rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, profiles/traffic_r1.json" if traffic else None,
                               "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
                               "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3), "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
