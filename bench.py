@@ -107,7 +107,7 @@ def main():
 
     ev_pairs = []   # (start,end) HIP events around every specular bake launch, on the launch stream
 
-    def step(record_events=False):
+    def step(record_events=False, gather=True):
         """One view: rays -> primary hits (this rank's stripes) -> 7 fused lobe kernels -> scatter -> one all_gather."""
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         xs, ds = xs[pix_local], ds[pix_local]
@@ -142,7 +142,7 @@ def main():
                 maps[m, g["sel"]] = res; m += 1
             else:
                 maps[m, g["sel"]] = res[0]; maps[m + 1, g["sel"]] = res[1]; m += 2
-        full = maps if (args.emulate_world > 1 and world == 1) else sh.gather_maps(maps, H, W, world, rank)
+        full = maps if (not gather or (args.emulate_world > 1 and world == 1)) else sh.gather_maps(maps, H, W, world, rank)
         return rays, full
 
     def sync():
@@ -163,7 +163,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0 and not args.no_roofline and any(l > 0 for l in lobes):
         for _ in range(2):                      # per-launch durations of the dominant kernel: separate, serialised pass (HIP events
-            step(record_events=True)            # on the launch stream); the timed region above overlaps launches on several streams
+            step(record_events=True, gather=False)   # on the launch stream); rank 0 only, hence no collective in this pass
         torch.cuda.synchronize()
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     rays_t = torch.tensor([rays_local], device=dev, dtype=torch.float64)
