@@ -83,11 +83,18 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (IRIS_BENCH_BACKEND=gloo lets a box with fewer GPUs than ranks exercise the N>1 control flow by
+    # sharing devices; it is a functional check only, never a measurement.)
+    backend = os.environ.get("IRIS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from iris_amd import bake_shading as bs
     from iris_amd import sharding as sh
@@ -271,6 +278,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
