@@ -20,6 +20,7 @@ struct BakeArgs {
     float* out0; float* out1; int64_t* tri_next;
     unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
     // v2 only
+    uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray results between trace and reduce
     unsigned int* tile_counter; // zeroed before the launch
     int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
@@ -37,9 +38,9 @@ __device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int
 struct RayOut { float r0, g0, b0, r1, g1, b1; };
 
 // One (pixel, sample): sample the lobe, trace, shade.  Everything between the uniforms and Le*g stays in registers.
-template <bool SPEC, bool COUNT, int LAYOUT, int LDS_DEPTH = kStackLds>
+template <bool SPEC, bool COUNT, int LAYOUT, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
 __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int s, f3 x, f3 n, f3 w, f3 t, f3 b, uint64_t base,
-                                               uint32_t* lds_stack, TraceStats* ts, uint32_t& n_rays) {
+                                               uint32_t* lds_stack, TraceStats* ts, uint32_t& n_rays, uint32_t* ovf = nullptr) {
     float u0, u1;
     if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
     else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
@@ -54,7 +55,7 @@ __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int
     // position + RayEpsilon*wi  (bake_shading.py:117, :180)
     f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
     const uint32_t steps0 = COUNT ? ts->nodes + ts->tris : 0;
-    Hit h = trace_bvh4<LAYOUT, COUNT, LDS_DEPTH>(a.sc, o, wi, lds_stack, ts);
+    Hit h = trace_bvh4<LAYOUT, COUNT, LDS_DEPTH, GLOBAL_OVF>(a.sc, o, wi, lds_stack, ts, ovf);
     if (COUNT) {
         n_rays++;
         // tail statistic: the wave lasts as long as its longest ray -> sum over waves of 64 * max(steps per lane)
@@ -163,10 +164,10 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
 }
 
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernel is compiled for (= workgroups per CU)
-#define IRIS_TILE_WAVES 5
+#define IRIS_TILE_WAVES 6
 #endif
-#ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernel (deeper stacks spill to scratch; <0.4 % of rays exceed 12)
-#define IRIS_TILE_STACK 12
+#ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernel; deeper entries go to the workgroup's slab in the workspace
+#define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
 #endif
 template <bool SPEC, bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
     const int spp = a.spp;
     constexpr int NC = SPEC ? 2 : 1;  // float4 per ray
     float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
+    uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock + tid;
     const int64_t n_tiles = (a.P + a.tile_px - 1) / a.tile_px;
     int lpp, ppw, rounds;
     reduce_geometry(spp, lpp, ppw, rounds);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
                 const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
                 f3 t, b;
                 normal_space(n, t, b);
-                RayOut o = shade_sample<SPEC, COUNT, LAYOUT, kTileStack>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
+                RayOut o = shade_sample<SPEC, COUNT, LAYOUT, kTileStack, true>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays, ovf);
                 float4* q = res + (size_t)r * NC;
                 q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
                 if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
@@ -308,7 +310,8 @@ struct ViewArgs {
 };
 
 template <bool SPEC, int LAYOUT, int TILE_STACK>
-__device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk) {
+__device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
+                                          uint32_t* ovf) {
     uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
     uint32_t* s_hist = s_stack + kTileRays / 4;
     uint32_t* s_cur = s_hist + 256;
@@ -369,7 +372,7 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
             const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
             f3 t, b;
             normal_space(n, t, b);
-            RayOut o = shade_sample<SPEC, false, LAYOUT, TILE_STACK>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays);
+            RayOut o = shade_sample<SPEC, false, LAYOUT, TILE_STACK, true>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays, ovf);
             float4* q = res + (size_t)r * NC;
             q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
             if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
@@ -405,14 +408,13 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
     }
 }
 
-// The view kernel needs only 77 VGPRs, which would allow 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B); with 24
-// resident waves per CU that configuration died with a GPU memory access fault on the pool's MI355X (5 waves / 10 entries and
-// 6 waves / 12 entries -- which is LDS-limited to 5 blocks -- both run clean), so it stays at the tile kernel's 5 / 12.
+// 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B of LDS per workgroup, 6 workgroups per CU); like the tile
+// kernel, stack entries beyond the LDS part go to the workgroup's slab in the workspace, so the kernel uses no private scratch.
 #ifndef IRIS_VIEW_WAVES
-#define IRIS_VIEW_WAVES 5
+#define IRIS_VIEW_WAVES 6
 #endif
 #ifndef IRIS_VIEW_STACK
-#define IRIS_VIEW_STACK 12
+#define IRIS_VIEW_STACK 10
 #endif
 template <int LAYOUT>
 __global__ __launch_bounds__(kBlock, IRIS_VIEW_WAVES) void bake_view_kernel(ViewArgs v) {
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(kBlock, IRIS_VIEW_WAVES) void bake_view_kernel(View
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
     float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
+    uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock + tid;   // no private scratch in this kernel
     for (;;) {
         __syncthreads();
         if (tid == 0) { s_tile = (int)atomicAdd(v.base.tile_counter, 1u); s_chunk = 0; }
@@ -435,8 +438,8 @@ __global__ __launch_bounds__(kBlock, IRIS_VIEW_WAVES) void bake_view_kernel(View
         BakeArgs a = v.base;
         a.spp = v.lobe[l].spp; a.rough = v.lobe[l].rough; a.stream_id = v.lobe[l].stream_id; a.tile_px = v.lobe[l].tile_px;
         a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr;
-        if (v.lobe[l].spec) view_tile<true, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk);
-        else view_tile<false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk);
+        if (v.lobe[l].spec) view_tile<true, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf);
+        else view_tile<false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf);
     }
 }
 

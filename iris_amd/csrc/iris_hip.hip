@@ -523,12 +523,17 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // ======================================================================================================
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
 static int view_grid_blocks() { return num_cus() * IRIS_VIEW_WAVES; }
+static uint64_t stack_ovf_bytes() {
+    return (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kStackCapacity - std::min(IRIS_TILE_STACK, IRIS_VIEW_STACK)) * kBlock * sizeof(uint32_t);
+}
 
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
     if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
     // [256 B counters][blocks x 8192 x (16|32) B per-ray results]
     // (packing the pixel tensors into 48-B records was measured 7 % SLOWER than reading pos/nrm/wo directly: not done)
-    return 256 + (uint64_t)bake_grid_blocks() * kTileRays * (specular ? 2 : 1) * sizeof(float4);
+    // + [blocks x (96 - LDS depth) x 256 dwords: traversal-stack entries beyond the LDS part]   (specular sizing also serves iris_bake_view)
+    const uint64_t blocks = (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks());
+    return 256 + blocks * kTileRays * (specular ? 2 : 1) * sizeof(float4) + stack_ovf_bytes();
 }
 
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
@@ -560,6 +565,7 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         a.tile_px = tile_px;
         a.tile_counter = (unsigned int*)workspace;
         a.scratch = (float4*)((char*)workspace + 256);
+        a.stack_ovf = (uint32_t*)((char*)workspace + need - stack_ovf_bytes());
         HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
         const int64_t n_tiles = (P + tile_px - 1) / tile_px;
         const int grid = (int)std::min<int64_t>(blocks, n_tiles);
@@ -604,6 +610,7 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     v.base.pos = pos; v.base.nrm = nrm; v.base.wo = wo; v.base.pix_id = pix_id; v.base.P = P; v.base.seed = seed;
     v.base.tile_counter = (unsigned int*)workspace;
     v.base.scratch = (float4*)((char*)workspace + 256);
+    v.base.stack_ovf = (uint32_t*)((char*)workspace + need - stack_ovf_bytes());
     v.n_lobes = n_lobes;
     const int blocks = view_grid_blocks();
     long long t = 0;

@@ -32,19 +32,27 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
     return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : 1.0f / d;
 }
 
-template <int LDS_DEPTH>
+// Per-lane stack: the first LDS_DEPTH entries in LDS; deeper entries (a few % of the rays at depth 10-12) either in a private
+// (scratch) array or -- GLOBAL_OVF, kernels that must not use scratch -- in a workgroup-private slab of the caller's workspace
+// laid out [entry][thread] so that the rare accesses coalesce.
+constexpr int kStackCapacity = kStackLds + kStackSpill;
+template <int LDS_DEPTH, bool GLOBAL_OVF = false>
 struct Stack {
     uint32_t* lds;  // &s_stack[threadIdx.x]
-    uint32_t spill[kStackLds + kStackSpill - LDS_DEPTH];
+    uint32_t* ovf;  // GLOBAL_OVF: &slab[threadIdx.x]
+    uint32_t spill[GLOBAL_OVF ? 1 : kStackCapacity - LDS_DEPTH];
     int sp;
     __device__ __forceinline__ void push(uint32_t v) {
         if (sp < LDS_DEPTH) lds[sp * kBlock] = v;
-        else spill[min(sp - LDS_DEPTH, kStackLds + kStackSpill - LDS_DEPTH - 1)] = v;
+        else if (GLOBAL_OVF) ovf[(size_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock] = v;
+        else spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)] = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return sp < LDS_DEPTH ? lds[sp * kBlock] : spill[min(sp - LDS_DEPTH, kStackLds + kStackSpill - LDS_DEPTH - 1)];
+        if (sp < LDS_DEPTH) return lds[sp * kBlock];
+        if (GLOBAL_OVF) return ovf[(size_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock];
+        return spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)];
     }
 };
 
@@ -101,13 +109,13 @@ constexpr int kPhaseMin = 16;
 constexpr int kLayoutF32 = 1, kLayoutQ8 = 3;
 __device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xffu); }
 
-template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds>
-__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr) {
+template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
+__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
     Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
     const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
     const float nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
     const bool px = ix >= 0.f, py = iy >= 0.f, pz = iz >= 0.f;
-    Stack<LDS_DEPTH> st; st.lds = lds_stack; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
     uint32_t cur = 0;  // root
     int k = 0;         // triangles of the current leaf already tested
     int max_sp = 0;
