@@ -204,6 +204,23 @@ IRIS_API int iris_voxel_histogram(const float *x, int64_t B, double voxel_min, d
 /* per-triangle sums of extract_emitter_ldr.py:90-95: out (F,3) += values (B,3) at idx (B); count (F) f32 nullable */
 IRIS_API int iris_scatter_add_rows(const float *values, const int64_t *idx, int64_t B, int64_t F, float *out, float *count, iris_stream_t);
 
+/* ---- 8(f)-3: the shading cache resident in HBM + the BRDF trainer's shading combine --------------------------- */
+/* Floats per packed row for R roughness levels (R <= 8): [d.rgb 0 | per level: spec0.rgb spec1.rgb], padded to 16 B (40 for R=6).
+ * The VALUES are the reference's (pixels, 3+6R) table of utils/dataset/scannetpp/dataset.py:359-377; the order is ours. */
+IRIS_API int iris_cache_row_floats(int R);
+/* pack the 1+2R maps (n,3) of one view into rows (n, iris_cache_row_floats(R)); spec0 / spec1 are HOST arrays of R device pointers */
+IRIS_API int iris_cache_pack(const float *diffuse, const float *const *spec0, const float *const *spec1, int64_t n, int R, float *rows,
+                    iris_stream_t);
+/* the loader's batch slice (dataset.py:409-414): out (B, 3+6R) = [diffuse | specular0 (R,3) | specular1 (R,3)] of rows[idx] (idx NULL = identity) */
+IRIS_API int iris_cache_gather(const float *rows, const int64_t *idx, int64_t B, int R, float *out, iris_stream_t);
+/* train_brdf_crf.py:195-203 fused with the slice: L (B,3) = kd*diffuse + ks*lerp_specular(spec0,rough) + lerp_specular(spec1,rough),
+ * kd = albedo*(1-metallic), ks = 0.04*(1-metallic) + albedo*metallic; albedo (B,3), metallic (B), roughness (B) */
+IRIS_API int iris_shade_cached_fwd(const float *rows, const int64_t *idx, const float *albedo, const float *metallic, const float *roughness,
+                          int64_t B, int R, float *L, iris_stream_t);
+/* its gradient for an incoming gL (B,3): g_albedo (B,3), g_metallic (B), g_roughness (B); any output may be NULL */
+IRIS_API int iris_shade_cached_bwd(const float *rows, const int64_t *idx, const float *albedo, const float *metallic, const float *roughness,
+                          const float *gL, int64_t B, int R, float *g_albedo, float *g_metallic, float *g_roughness, iris_stream_t);
+
 /* ---- misc --------------------------------------------------------------------------------------------- */
 /* Philox uniforms exactly as the bake kernels draw them (for tests): u2[i] = U(seed, idx0+i, stream_id). */
 IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream_id, int64_t n, float *u2, iris_stream_t);

@@ -60,6 +60,11 @@ PROTOTYPES = {
     "iris_slf_scatter_add": [_P, _P, _P, _I64, _P, _P, _P],
     "iris_voxel_histogram": [_P, _I64, _D, _D, _I32, _P, _P],
     "iris_scatter_add_rows": [_P, _P, _I64, _I64, _P, _P, _P],
+    "iris_cache_row_floats": [_I32],
+    "iris_cache_pack": [_P, _P, _P, _I64, _I32, _P, _P],
+    "iris_cache_gather": [_P, _P, _I64, _I32, _P, _P],
+    "iris_shade_cached_fwd": [_P, _P, _P, _P, _P, _I64, _I32, _P, _P],
+    "iris_shade_cached_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P],
     "iris_last_error": [],
     "iris_version": [],
 }

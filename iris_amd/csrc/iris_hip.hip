@@ -15,6 +15,7 @@
 #include "iris_trace.h"
 #include "iris_bake.h"
 #include "iris_pt.h"
+#include "iris_cache.h"
 
 using namespace iris;
 
@@ -499,6 +500,51 @@ extern "C" IRIS_API int iris_lerp_specular(const float* specular, const float* r
     if (B < 0 || R < 1 || (B > 0 && (!specular || !roughness || !out))) return fail(IRIS_ERR_ARG, "iris_lerp_specular: bad arguments");
     if (B == 0) return IRIS_OK;
     hipLaunchKernelGGL(lerp_specular_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, specular, roughness, B, R, out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+// ---- 8(f)-3: packed shading cache + shading combine (iris_cache.h)
+extern "C" IRIS_API int iris_cache_row_floats(int R) { return (R < 1 || R > kMaxLevels) ? 0 : cache_row_floats(R); }
+extern "C" IRIS_API int iris_cache_pack(const float* diffuse, const float* const* spec0, const float* const* spec1, int64_t n, int R, float* rows,
+                                        iris_stream_t stream) {
+    if (n < 0 || R < 1 || R > kMaxLevels || (n > 0 && (!diffuse || !spec0 || !spec1 || !rows))) return fail(IRIS_ERR_ARG, "iris_cache_pack: bad arguments");
+    if (n == 0) return IRIS_OK;
+    CacheMaps m{};
+    m.diffuse = diffuse;
+    for (int j = 0; j < R; ++j) {
+        if (!spec0[j] || !spec1[j]) return fail(IRIS_ERR_ARG, "iris_cache_pack: null map");
+        m.s0[j] = spec0[j]; m.s1[j] = spec1[j];
+    }
+    hipLaunchKernelGGL(cache_pack_kernel, dim3(grid_for(n * (cache_row_floats(R) / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, m, n, R, rows);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_cache_gather(const float* rows, const int64_t* idx, int64_t B, int R, float* out, iris_stream_t stream) {
+    if (B < 0 || R < 1 || R > kMaxLevels || (B > 0 && (!rows || !out))) return fail(IRIS_ERR_ARG, "iris_cache_gather: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(cache_gather_kernel, dim3(grid_for(B * (3 + 6 * R), 256, 16384)), dim3(256), 0, (hipStream_t)stream, rows, idx, B, R, out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_shade_cached_fwd(const float* rows, const int64_t* idx, const float* albedo, const float* metallic,
+                                              const float* roughness, int64_t B, int R, float* L, iris_stream_t stream) {
+    if (B < 0 || R < 1 || R > kMaxLevels || (B > 0 && (!rows || !albedo || !metallic || !roughness || !L)))
+        return fail(IRIS_ERR_ARG, "iris_shade_cached_fwd: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(shade_cached_fwd_kernel, dim3(grid_for(B, 256, 16384)), dim3(256), 0, (hipStream_t)stream, rows, idx, albedo, metallic,
+                       roughness, B, R, L);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_shade_cached_bwd(const float* rows, const int64_t* idx, const float* albedo, const float* metallic,
+                                              const float* roughness, const float* gL, int64_t B, int R, float* g_albedo, float* g_metallic,
+                                              float* g_roughness, iris_stream_t stream) {
+    if (B < 0 || R < 1 || R > kMaxLevels || (B > 0 && (!rows || !albedo || !metallic || !roughness || !gL)))
+        return fail(IRIS_ERR_ARG, "iris_shade_cached_bwd: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(shade_cached_bwd_kernel, dim3(grid_for(B, 256, 16384)), dim3(256), 0, (hipStream_t)stream, rows, idx, albedo, metallic,
+                       roughness, gL, B, R, g_albedo, g_metallic, g_roughness);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

@@ -309,6 +309,85 @@ ORC_API void orc_lerp_specular(const float *spec, const float *rough, int64_t B,
     }
 }
 
+/* --------------------------------------------------------------------------------------------
+ * 8(f)-3  packed shading cache + the BRDF trainer's shading combine
+ * Packing (utils/dataset/scannetpp/dataset.py:359-377): per pixel diffuse(3) | spec0 level 0..R-1 (3 each) | spec1 level 0..R-1.
+ * The oracle keeps the reference's (3+6R)-float row; the HIP library keeps its own padded / level-interleaved row and must
+ * return the same values.  Slice (:409-414) = row gather by pixel index.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_cache_pack(const float *diffuse, const float *const *spec0, const float *const *spec1, int64_t n, int R, float *rows) {
+    const int S = 3 + 6 * R;
+    for (int64_t i = 0; i < n; ++i) {
+        float *q = rows + i * S;
+        for (int c = 0; c < 3; ++c) q[c] = diffuse[i * 3 + c];
+        for (int j = 0; j < R; ++j)
+            for (int c = 0; c < 3; ++c) { q[3 + j * 3 + c] = spec0[j][i * 3 + c]; q[3 + 3 * R + j * 3 + c] = spec1[j][i * 3 + c]; }
+    }
+}
+ORC_API void orc_cache_gather(const float *rows, const int64_t *idx, int64_t B, int R, float *out) {
+    const int S = 3 + 6 * R;
+    for (int64_t i = 0; i < B; ++i) memcpy(out + i * S, rows + (idx ? idx[i] : i) * S, (size_t)S * sizeof(float));
+}
+
+typedef struct { int64_t r0, r1; float w; } lerp_pos;
+static lerp_pos lerp_position(float rough, int R) { /* utils/ops.py:108-115 */
+    lerp_pos p;
+    float r = (rough - 0.02f) / (float)(1.0 - 0.02) * (float)(R - 1);
+    p.r1 = (int64_t)ceilf(r); p.r0 = (int64_t)floorf(r);
+    p.w = r - (float)p.r0;
+    /* out-of-range roughness: clamp (the reference would index out of range) */
+    if (p.r0 < 0) p.r0 = 0;
+    if (p.r1 < 0) p.r1 = 0;
+    if (p.r0 > R - 1) p.r0 = R - 1;
+    if (p.r1 > R - 1) p.r1 = R - 1;
+    return p;
+}
+
+/* train_brdf_crf.py:195-203: kd = albedo*(1-metallic); ks = 0.04*(1-metallic) + albedo*metallic;
+ * L = kd*diffuse + ks*lerp_specular(specular0, roughness) + lerp_specular(specular1, roughness)     (rows in the (3+6R) layout) */
+ORC_API void orc_shade_cached_fwd(const float *rows, const int64_t *idx, const float *albedo, const float *metallic, const float *roughness,
+                                  int64_t B, int R, float *L) {
+    const int S = 3 + 6 * R;
+    for (int64_t i = 0; i < B; ++i) {
+        const float *q = rows + (idx ? idx[i] : i) * S;
+        lerp_pos p = lerp_position(roughness[i], R);
+        float m = metallic[i], m1 = 1.f - m;
+        for (int c = 0; c < 3; ++c) {
+            float a = albedo[i * 3 + c];
+            float kd = a * m1, ks = 0.04f * m1 + a * m;
+            float S0 = q[3 + p.r0 * 3 + c] * (1.f - p.w) + q[3 + p.r1 * 3 + c] * p.w;
+            float S1 = q[3 + 3 * R + p.r0 * 3 + c] * (1.f - p.w) + q[3 + 3 * R + p.r1 * 3 + c] * p.w;
+            float Ld = kd * q[c], Ls = ks * S0 + S1;
+            L[i * 3 + c] = Ld + Ls;
+        }
+    }
+}
+/* gradient of the above w.r.t. albedo (B,3), metallic (B), roughness (B) for an incoming gL (B,3); fixed summation order c = 0,1,2 */
+ORC_API void orc_shade_cached_bwd(const float *rows, const int64_t *idx, const float *albedo, const float *metallic, const float *roughness,
+                                  const float *gL, int64_t B, int R, float *g_albedo, float *g_metallic, float *g_roughness) {
+    const int S = 3 + 6 * R;
+    for (int64_t i = 0; i < B; ++i) {
+        const float *q = rows + (idx ? idx[i] : i) * S;
+        lerp_pos p = lerp_position(roughness[i], R);
+        float m = metallic[i], m1 = 1.f - m;
+        float g_m = 0.f, g_m1 = 0.f, g_w = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            float a = albedo[i * 3 + c], g = gL[i * 3 + c];
+            float s0a = q[3 + p.r0 * 3 + c], s0b = q[3 + p.r1 * 3 + c];
+            float s1a = q[3 + 3 * R + p.r0 * 3 + c], s1b = q[3 + 3 * R + p.r1 * 3 + c];
+            float S0 = s0a * (1.f - p.w) + s0b * p.w;
+            float ks = 0.04f * m1 + a * m;
+            float g_kd = g * q[c], g_ks = g * S0;
+            g_albedo[i * 3 + c] = g_kd * m1 + g_ks * m;
+            g_m += g_ks * a;
+            g_m1 += g_kd * a + g_ks * 0.04f;
+            g_w += (g * ks) * (s0b - s0a) + g * (s1b - s1a);
+        }
+        g_metallic[i] = g_m - g_m1;
+        g_roughness[i] = g_w * (float)(R - 1) / (float)(1.0 - 0.02);
+    }
+}
+
 /* ============================================================================================
  * a5  VoxelSLF (model/slf.py) and SLFEmitter.eval_emitter (model/emitter.py)
  * ========================================================================================== */

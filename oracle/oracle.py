@@ -128,6 +128,41 @@ def lerp_specular(specular, roughness):
     return out
 
 
+# ---------------------------------------------------------------- 8(f)-3 packed shading cache + shading combine
+def cache_pack(diffuse, spec0, spec1):
+    """13 maps (n,3) -> rows (n, 3+6R) in the reference's order (utils/dataset/scannetpp/dataset.py:359-377)."""
+    diffuse = _f32(diffuse); spec0 = [_f32(m) for m in spec0]; spec1 = [_f32(m) for m in spec1]
+    n, R = diffuse.shape[0], len(spec0)
+    rows = np.empty((n, 3 + 6 * R), np.float32)
+    a0 = (C.c_void_p * R)(*[m.ctypes.data for m in spec0]); a1 = (C.c_void_p * R)(*[m.ctypes.data for m in spec1])
+    lib().orc_cache_pack(_p(diffuse), a0, a1, C.c_int64(n), C.c_int(R), _p(rows))
+    return rows
+
+
+def cache_gather(rows, idx):
+    rows = _f32(rows); idx = np.ascontiguousarray(idx, dtype=np.int64)
+    R = (rows.shape[1] - 3) // 6
+    out = np.empty((len(idx), rows.shape[1]), np.float32)
+    lib().orc_cache_gather(_p(rows), _p(idx), C.c_int64(len(idx)), C.c_int(R), _p(out))
+    return out
+
+
+def shade_cached(rows, idx, albedo, metallic, roughness, gL=None):
+    """train_brdf_crf.py:195-203 on rows of the packed cache; with gL also the gradients (g_albedo, g_metallic, g_roughness)."""
+    rows = _f32(rows); albedo = _f32(albedo); metallic = _f32(metallic).reshape(-1); roughness = _f32(roughness).reshape(-1)
+    idx = None if idx is None else np.ascontiguousarray(idx, dtype=np.int64)
+    B, R = albedo.shape[0], (rows.shape[1] - 3) // 6
+    L = np.empty((B, 3), np.float32)
+    ip = _p(idx) if idx is not None else None
+    lib().orc_shade_cached_fwd(_p(rows), ip, _p(albedo), _p(metallic), _p(roughness), C.c_int64(B), C.c_int(R), _p(L))
+    if gL is None:
+        return L
+    gL = _f32(gL)
+    ga = np.empty((B, 3), np.float32); gm = np.empty((B, 1), np.float32); gr = np.empty((B, 1), np.float32)
+    lib().orc_shade_cached_bwd(_p(rows), ip, _p(albedo), _p(metallic), _p(roughness), _p(gL), C.c_int64(B), C.c_int(R), _p(ga), _p(gm), _p(gr))
+    return L, ga, gm, gr
+
+
 # ---------------------------------------------------------------- a5
 class VoxelSLF:
     def __init__(self, inds, radiance, voxel_min, voxel_max):

@@ -407,6 +407,35 @@ def main():
     np.savez(os.path.join(OUT, "slf_scatter.npz"), mask=maskq.numpy(), voxel_min=-0.3, voxel_max=2.9, x=cen.numpy(), rgb=radq.numpy(),
              radiance=vq.radiance.numpy(), count=vq.count.numpy())
 
+    # ------------------------------------------------------------------ 8(f)-3: shading combine of the BRDF trainer
+    # train_brdf_crf.py:195-203 replayed through the reference's lerp_specular on rows cut from a packed cache exactly as
+    # utils/dataset/scannetpp/dataset.py:359-377 (pack) and :409-414 (slice) do; gradients by torch.autograd.
+    torch.manual_seed(7)
+    Bc, Rl = 512, 6
+    maps = [torch.rand(Bc, 3) * 2 for _ in range(1 + 2 * Rl)]                 # diffuse, spec0[0..5], spec1[0..5] of one "view"
+    all_cache = torch.cat([maps[0], torch.cat(maps[1:1 + Rl], -1), torch.cat(maps[1 + Rl:], -1)], 1)   # (B,39)
+    idxc = torch.randperm(Bc)[:384]
+    cache = all_cache[idxc]
+    diffuse_c = cache[..., :3]
+    specular0 = cache[..., 3:21].reshape(len(idxc), -1, 3)
+    specular1 = cache[..., 21:39].reshape(len(idxc), -1, 3)
+    albedo = torch.rand(len(idxc), 3).requires_grad_(True)
+    metallic = torch.rand(len(idxc), 1).requires_grad_(True)
+    rough_c = (torch.rand(len(idxc), 1) * 0.98 + 0.02)
+    rough_c[0] = 0.02; rough_c[1] = 1.0; rough_c[2] = 0.216; rough_c[3] = 0.412; rough_c[4] = 0.5; rough_c[5] = 0.999999
+    rough_c.requires_grad_(True)
+    kd = albedo * (1 - metallic)
+    ks = 0.04 * (1 - metallic) + albedo * metallic
+    Ld = kd * diffuse_c
+    Ls = ks * rops.lerp_specular(specular0, rough_c) + rops.lerp_specular(specular1, rough_c)
+    Lc = Ld + Ls
+    gLc = torch.randn(len(idxc), 3)
+    ga, gm, gr = torch.autograd.grad(Lc, [albedo, metallic, rough_c], gLc)
+    np.savez(os.path.join(OUT, "shade_cached.npz"), **{f"map_{i}": m.numpy() for i, m in enumerate(maps)}, all_cache=all_cache.numpy(),
+             idx=idxc.numpy(), diffuse=diffuse_c.numpy(), specular0=specular0.numpy(), specular1=specular1.numpy(),
+             albedo=albedo.detach().numpy(), metallic=metallic.detach().numpy(), roughness=rough_c.detach().numpy(), L=Lc.detach().numpy(),
+             gL=gLc.numpy(), g_albedo=ga.numpy(), g_metallic=gm.numpy(), g_roughness=gr.numpy())
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
