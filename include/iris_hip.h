@@ -221,6 +221,16 @@ IRIS_API int iris_shade_cached_fwd(const float *rows, const int64_t *idx, const 
 IRIS_API int iris_shade_cached_bwd(const float *rows, const int64_t *idx, const float *albedo, const float *metallic, const float *roughness,
                           const float *gL, int64_t B, int R, float *g_albedo, float *g_metallic, float *g_roughness, iris_stream_t);
 
+/* ---- 8(f)-4: denoiser substitute for mitsuba.OptixDenoiser (bake_shading.py:81,129,198-200) --------------------- */
+/* Variance-guided edge-avoiding a-trous filter over (H,W,3) maps, guided by the primary hits of the view: normal / position (H*W,3) f32
+ * and valid (H*W) u8 (each nullable: no guide of that kind).  in / out: HOST arrays of n_maps device pointers (in[m] == out[m] allowed);
+ * maps are filtered four at a time sharing the geometric weights.  iterations in [1,8] (stride 2^i); defaults used by the Python
+ * mirror: 5, sigma_l 4, sigma_n 64, sigma_p 0.1.  Not bit-comparable with OptiX (closed): judged on PSNR against a high-spp bake. */
+IRIS_API uint64_t iris_denoise_workspace_bytes(int H, int W);
+IRIS_API int iris_denoise(const float *normal, const float *position, const uint8_t *valid, int H, int W, int n_maps, const float *const *in,
+                 float *const *out, int iterations, float sigma_l, float sigma_n, float sigma_p, void *workspace, uint64_t workspace_bytes,
+                 iris_stream_t);
+
 /* ---- misc --------------------------------------------------------------------------------------------- */
 /* Philox uniforms exactly as the bake kernels draw them (for tests): u2[i] = U(seed, idx0+i, stream_id). */
 IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream_id, int64_t n, float *u2, iris_stream_t);

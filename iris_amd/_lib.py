@@ -65,11 +65,13 @@ PROTOTYPES = {
     "iris_cache_gather": [_P, _P, _I64, _I32, _P, _P],
     "iris_shade_cached_fwd": [_P, _P, _P, _P, _P, _I64, _I32, _P, _P],
     "iris_shade_cached_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P],
+    "iris_denoise_workspace_bytes": [_I32, _I32],
+    "iris_denoise": [_P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _F, _F, _F, _P, _U64, _P],
     "iris_last_error": [],
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
 
 _lib = None
 

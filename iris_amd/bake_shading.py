@@ -157,10 +157,12 @@ def primary_hits(scene, xs, ds, pixel_ids=None, image_width=None, block=8):
 
 
 def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=None, seed=0, pixel_ids=None, lobes=None,
-              image_width=None, n_streams=3):
+              image_width=None, n_streams=3, denoiser=None):
     """One view: the primary pass once (the reference repeats it, :98 and :154), then the diffuse lobe and the six
     specular roughness levels.  Returns {'diffuse': (N,3), 'specular0': [6x (N,3)], 'specular1': [...], 'n_valid', 'rays'}
-    with N = len(xs) rows in the caller's pixel order (zeros at invalid pixels, bake_shading.py:126-127)."""
+    with N = len(xs) rows in the caller's pixel order (zeros at invalid pixels, bake_shading.py:126-127).
+    denoiser: a utils.denoise.Denoiser for the full image (xs must then be all H*W pixels in image order): filters the diffuse map
+    and the specular maps of roughness levels > 0 as the reference does (:129, :198-200), guided by this view's primary hits."""
     spps = list(SPPS_SPECULAR if spps_specular is None else spps_specular)
     g = primary_hits(scene, xs, ds, pixel_ids, image_width=image_width)
     N, dev = xs.shape[0], xs.device
@@ -195,6 +197,21 @@ def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=Non
             out["diffuse"] = scatter(res)
         else:
             out["specular0"].append(scatter(res[0])); out["specular1"].append(scatter(res[1]))
+    if denoiser is not None:
+        if pixel_ids is not None or N != denoiser.H * denoiser.W:
+            raise L.IrisError("bake_view: denoising needs the whole image in image order")
+        valid = torch.zeros(N, dtype=torch.bool, device=dev); valid[g["sel"]] = True
+        denoiser.set_guides(scatter(g["normal"]), scatter(g["position"]), valid)
+        names = [("diffuse", None)] if "diffuse" in out else []
+        lv = [l for l in want if l > 1]                    # "no need for denoise of low roughness" (:198): level index 0 stays as baked
+        order = [l for l in want if l > 0]
+        names += [(k, order.index(l)) for l in lv for k in ("specular0", "specular1")]
+        den = denoiser.denoise_maps([out[k] if i is None else out[k][i] for k, i in names])
+        for (k, i), d in zip(names, den):
+            if i is None:
+                out[k] = d.reshape(N, 3)
+            else:
+                out[k][i] = d.reshape(N, 3)
     return out
 
 
@@ -229,6 +246,8 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--compression", type=str, default="zip", choices=["none", "zips", "zip"])
     parser.add_argument("--overwrite", action="store_true", help="re-bake views whose 13 files already exist")
+    parser.add_argument("--denoise", type=str, default="atrous", choices=["atrous", "none"],
+                        help="atrous: guided a-trous filter in place of the reference's OptiX denoiser (:129, :198-200); none: raw Monte-Carlo maps")
     args = parser.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +282,10 @@ def main(argv=None):
     os.makedirs(os.path.join(args.output, "diffuse"), exist_ok=True)
     os.makedirs(os.path.join(args.output, "specular"), exist_ok=True)
 
+    denoiser = None
+    if args.denoise == "atrous":
+        from .utils.denoise import Denoiser
+        denoiser = Denoiser(img_hw[::-1], device)          # denoiser = mitsuba.OptixDenoiser(img_hw[::-1])   (:81)
     start_time = time.time()
     rays = 0
     for im_id in range(rank, len(views), world):           # views shard over ranks with no collective: one file set per view
@@ -270,9 +293,8 @@ def main(argv=None):
         if not args.overwrite and all(os.path.exists(f) for f in files):
             continue
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
-        out = bake_view(scene, emitter, xs, ds, args.spp_diffuse, args.spps_specular, seed=args.seed, image_width=img_hw[1])
+        out = bake_view(scene, emitter, xs, ds, args.spp_diffuse, args.spps_specular, seed=args.seed, image_width=img_hw[1], denoiser=denoiser)
         rays += out["rays"]
-        # pre-denoise maps: the OptiX AI denoiser of the reference (:129, :198-200) has no AMD counterpart
         exr.write_exr(files[0], out["diffuse"].reshape(*img_hw, 3).cpu().numpy(), args.compression)
         for r in range(N_ROUGHNESS):
             exr.write_exr(files[1 + 2 * r], out["specular0"][r].reshape(*img_hw, 3).cpu().numpy(), args.compression)

@@ -16,6 +16,7 @@
 #include "iris_bake.h"
 #include "iris_pt.h"
 #include "iris_cache.h"
+#include "iris_denoise.h"
 
 using namespace iris;
 
@@ -545,6 +546,54 @@ extern "C" IRIS_API int iris_shade_cached_bwd(const float* rows, const int64_t* 
     if (B == 0) return IRIS_OK;
     hipLaunchKernelGGL(shade_cached_bwd_kernel, dim3(grid_for(B, 256, 16384)), dim3(256), 0, (hipStream_t)stream, rows, idx, albedo, metallic,
                        roughness, gL, B, R, g_albedo, g_metallic, g_roughness);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+// ---- 8(f)-4: denoiser substitute (iris_denoise.h)
+extern "C" IRIS_API uint64_t iris_denoise_workspace_bytes(int H, int W) {
+    if (H < 1 || W < 1) return 0;
+    return (uint64_t)H * W * (2 + 2 * kDnMaxMaps) * sizeof(float4);
+}
+template <int M>
+static void denoise_group(const DnParams& P, const DnMaps& mp, const float4* g0, const float4* g1, int iterations, hipStream_t st) {
+    const dim3 grid((P.W + 15) / 16, (P.H + 15) / 16), block(256);
+    hipLaunchKernelGGL((dn_variance_kernel<M>), grid, block, 0, st, P, mp, g0, g1);
+    DnMaps cur = mp;
+    for (int it = 0; it < iterations; ++it) {
+        if (it == iterations - 1) hipLaunchKernelGGL((dn_atrous_kernel<M, true>), grid, block, 0, st, P, cur, g0, g1, 1 << it);
+        else hipLaunchKernelGGL((dn_atrous_kernel<M, false>), grid, block, 0, st, P, cur, g0, g1, 1 << it);
+        for (int m = 0; m < M; ++m) std::swap(cur.a[m], cur.b[m]);
+    }
+}
+extern "C" IRIS_API int iris_denoise(const float* normal, const float* position, const uint8_t* valid, int H, int W, int n_maps,
+                                     const float* const* in, float* const* out, int iterations, float sigma_l, float sigma_n, float sigma_p,
+                                     void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
+    if (H < 1 || W < 1 || n_maps < 0 || iterations < 1 || iterations > 8 || !(sigma_l > 0.f) || !(sigma_n >= 0.f) || !(sigma_p > 0.f) ||
+        (n_maps > 0 && (!in || !out)))
+        return fail(IRIS_ERR_ARG, "iris_denoise: bad arguments");
+    if (!workspace || workspace_bytes < iris_denoise_workspace_bytes(H, W))
+        return fail(IRIS_ERR_ARG, "iris_denoise: workspace of iris_denoise_workspace_bytes() bytes required");
+    if (n_maps == 0) return IRIS_OK;
+    for (int m = 0; m < n_maps; ++m) if (!in[m] || !out[m]) return fail(IRIS_ERR_ARG, "iris_denoise: null map");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)H * W;
+    float4* g0 = (float4*)workspace;
+    float4* g1 = g0 + n;
+    float4* bufs = g1 + n;
+    hipLaunchKernelGGL(dn_guides_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, normal, position, valid, n, g0, g1);
+    DnParams P{H, W, sigma_l, sigma_n, sigma_p};
+    for (int m0 = 0; m0 < n_maps; m0 += kDnMaxMaps) {
+        const int M = std::min(kDnMaxMaps, n_maps - m0);
+        DnMaps mp{};
+        for (int m = 0; m < M; ++m) { mp.in[m] = in[m0 + m]; mp.out[m] = out[m0 + m]; mp.a[m] = bufs + (int64_t)(2 * m) * n; mp.b[m] = bufs + (int64_t)(2 * m + 1) * n; }
+        switch (M) {
+            case 1: denoise_group<1>(P, mp, g0, g1, iterations, st); break;
+            case 2: denoise_group<2>(P, mp, g0, g1, iterations, st); break;
+            case 3: denoise_group<3>(P, mp, g0, g1, iterations, st); break;
+            default: denoise_group<4>(P, mp, g0, g1, iterations, st); break;
+        }
+    }
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

@@ -388,6 +388,104 @@ ORC_API void orc_shade_cached_bwd(const float *rows, const int64_t *idx, const f
     }
 }
 
+/* --------------------------------------------------------------------------------------------
+ * 8(f)-4  denoiser substitute.  NO reference counterpart can be restated: bake_shading.py:81,129,198-200 call the closed OptiX AI
+ * denoiser.  This is the CPU restatement of the BUILD'S OWN filter (iris_amd/csrc/iris_denoise.h: variance-guided edge-avoiding
+ * a-trous), used to check the HIP kernels tap for tap (tolerance: expf / log2f differ in the last ulp between libm and the device);
+ * quality is judged separately on PSNR against a high-spp bake.  "parity unpinned" by construction.
+ * ------------------------------------------------------------------------------------------ */
+static float dn_lum(const float *c) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
+typedef struct { int H, W; float sigma_l, sigma_n, sigma_p; const float *normal, *position; const uint8_t *valid; } dn_ctx;
+static int dn_valid(const dn_ctx *d, int64_t q) { return d->valid ? d->valid[q] != 0 : 1; }
+static void dn_guide(const dn_ctx *d, int64_t q, float *n, float *x) {
+    if (d->normal && dn_valid(d, q)) { n[0] = d->normal[q * 3]; n[1] = d->normal[q * 3 + 1]; n[2] = d->normal[q * 3 + 2]; } else { n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; }
+    if (d->position && dn_valid(d, q)) { x[0] = d->position[q * 3]; x[1] = d->position[q * 3 + 1]; x[2] = d->position[q * 3 + 2]; } else { x[0] = x[1] = x[2] = 0.f; }
+}
+static float dn_geo(const dn_ctx *d, int64_t p, int64_t q) {
+    if (!dn_valid(d, q)) return 0.f;
+    float np[3], xp[3], nq[3], xq[3];
+    dn_guide(d, p, np, xp); dn_guide(d, q, nq, xq);
+    float nn = fmaxf(0.f, np[0] * nq[0] + np[1] * nq[1] + np[2] * nq[2]);
+    float wn = nn > 0.f ? exp2f(d->sigma_n * log2f(nn)) : 0.f;
+    float dx = xq[0] - xp[0], dy = xq[1] - xp[1], dz = xq[2] - xp[2];
+    float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    float plane = fabsf(np[0] * dx + np[1] * dy + np[2] * dz);
+    return wn * expf(-plane / (d->sigma_p * dist + 1e-12f));
+}
+/* one map: in (H*W,3) -> out (H*W,3) */
+ORC_API void orc_denoise(const float *normal, const float *position, const uint8_t *valid, int H, int W, const float *in, float *out,
+                         int iterations, float sigma_l, float sigma_n, float sigma_p) {
+    dn_ctx d = {H, W, sigma_l, sigma_n, sigma_p, normal, position, valid};
+    const int64_t n = (int64_t)H * W;
+    float *a = (float *)calloc((size_t)n * 4, sizeof(float)), *b = (float *)calloc((size_t)n * 4, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int64_t p = (int64_t)y * W + x;
+            if (!dn_valid(&d, p)) continue;
+            float ws = 0.f, m1 = 0.f, m2 = 0.f;
+            for (int dy = -3; dy <= 3; ++dy) {
+                int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -3; dx <= 3; ++dx) {
+                    int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    int64_t q = (int64_t)yy * W + xx;
+                    float w = (dx == 0 && dy == 0) ? 1.f : dn_geo(&d, p, q);
+                    if (w == 0.f) continue;
+                    float l = dn_lum(in + q * 3);
+                    ws += w; m1 += w * l; m2 += w * l * l;
+                }
+            }
+            float mean = m1 / ws;
+            a[p * 4] = in[p * 3]; a[p * 4 + 1] = in[p * 3 + 1]; a[p * 4 + 2] = in[p * 3 + 2];
+            a[p * 4 + 3] = fmaxf(0.f, m2 / ws - mean * mean);
+        }
+    const float h1[3] = {3.f / 8.f, 1.f / 4.f, 1.f / 16.f};
+    const float hc = h1[0] * h1[0];
+    for (int it = 0; it < iterations; ++it) {
+        const int step = 1 << it;
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                int64_t p = (int64_t)y * W + x;
+                if (!dn_valid(&d, p)) { b[p * 4] = b[p * 4 + 1] = b[p * 4 + 2] = b[p * 4 + 3] = 0.f; continue; }
+                float gw = 0.f, gv = 0.f;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        int xx = x + dx, yy = y + dy;
+                        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                        int64_t q = (int64_t)yy * W + xx;
+                        if (!dn_valid(&d, q)) continue;
+                        float k = (dx == 0 ? 2.f : 1.f) * (dy == 0 ? 2.f : 1.f);
+                        gw += k; gv += k * a[q * 4 + 3];
+                    }
+                float lp = dn_lum(a + p * 4);
+                float inv_sl = 1.f / (sigma_l * sqrtf(fmaxf(0.f, gv / gw)) + 1e-6f);
+                float sr = a[p * 4], sg = a[p * 4 + 1], sb = a[p * 4 + 2], sv = a[p * 4 + 3], sw = 1.f;
+                for (int j = -2; j <= 2; ++j) {
+                    int yy = y + j * step;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int i = -2; i <= 2; ++i) {
+                        int xx = x + i * step;
+                        if (xx < 0 || xx >= W || (i == 0 && j == 0)) continue;
+                        int64_t q = (int64_t)yy * W + xx;
+                        float wg = dn_geo(&d, p, q);
+                        if (wg == 0.f) continue;
+                        float h = h1[i < 0 ? -i : i] * h1[j < 0 ? -j : j] / hc * wg;
+                        float w = h * expf(-fabsf(lp - dn_lum(a + q * 4)) * inv_sl);
+                        sr += w * a[q * 4]; sg += w * a[q * 4 + 1]; sb += w * a[q * 4 + 2]; sv += w * w * a[q * 4 + 3]; sw += w;
+                    }
+                }
+                float inv = 1.f / sw;
+                b[p * 4] = sr * inv; b[p * 4 + 1] = sg * inv; b[p * 4 + 2] = sb * inv; b[p * 4 + 3] = sv * inv * inv;
+            }
+        float *t = a; a = b; b = t;
+    }
+    for (int64_t p = 0; p < n; ++p) { out[p * 3] = a[p * 4]; out[p * 3 + 1] = a[p * 4 + 1]; out[p * 3 + 2] = a[p * 4 + 2]; }
+    free(a); free(b);
+}
+
 /* ============================================================================================
  * a5  VoxelSLF (model/slf.py) and SLFEmitter.eval_emitter (model/emitter.py)
  * ========================================================================================== */

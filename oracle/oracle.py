@@ -163,6 +163,19 @@ def shade_cached(rows, idx, albedo, metallic, roughness, gL=None):
     return L, ga, gm, gr
 
 
+# ---------------------------------------------------------------- 8(f)-4 denoiser substitute (the build's own filter; no reference counterpart)
+def denoise(img, normal=None, position=None, valid=None, iterations=5, sigma_l=4.0, sigma_n=64.0, sigma_p=0.1):
+    img = _f32(img); H, W, _ = img.shape
+    out = np.empty_like(img)
+    normal = None if normal is None else _f32(normal).reshape(-1, 3)
+    position = None if position is None else _f32(position).reshape(-1, 3)
+    valid = None if valid is None else np.ascontiguousarray(np.asarray(valid).reshape(-1), dtype=np.uint8)
+    lib().orc_denoise(_p(normal) if normal is not None else None, _p(position) if position is not None else None,
+                      _p(valid) if valid is not None else None, C.c_int(H), C.c_int(W), _p(img), _p(out), C.c_int(iterations),
+                      C.c_float(sigma_l), C.c_float(sigma_n), C.c_float(sigma_p))
+    return out
+
+
 # ---------------------------------------------------------------- a5
 class VoxelSLF:
     def __init__(self, inds, radiance, voxel_min, voxel_max):
