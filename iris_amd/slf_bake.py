@@ -1,0 +1,112 @@
+"""The stages BEFORE the bake, on the device: they write the two files the bake loads.
+
+  bake_slf         slf_bake.py:69-145          scene bounds -> occupancy histogram -> VoxelSLF mean-pooled radiance -> vslf.npz
+  refine_slf       slf_refine.py:85-108        re-pool an existing grid with new radiance
+  extract_emitters extract_emitter_ldr.py:72-115  per-triangle mean radiance -> threshold -> emitter.pth
+
+`views` is any iterable of dicts with 'rays' (N,6) [origin, direction] and, where radiance is pooled, 'rgbs' (N,3) LINEAR radiance:
+the reference obtains it with ``model_crf.inverse(rgbs, exposure)`` (slf_bake.py:128-129) -- the learned camera response model and
+the image datasets are outside this path, the caller applies them.  Primary rays are traced with the HIP intersector; pooling is
+atomic accumulation in HBM (utils/gbuffer.py, VoxelSLF.scatter_add), so float sums agree with the reference's sequential CPU
+scatter up to summation order, integer results exactly.  Everything stays on the device; only the final state dict goes to the
+host, in the reference's file format (so SLFEmitter(emitter_path, slf_path) loads either side's files).
+"""
+import torch
+import torch.nn.functional as NF
+
+from . import _lib as L
+from .model.slf import VoxelSLF
+from .utils.gbuffer import scatter_add_rows, voxel_histogram
+from .utils.path_tracing import ray_intersect
+
+
+def _hits(scene, batch, device):
+    rays = batch["rays"].to(device)
+    positions, _, _, idx, valid = ray_intersect(scene, rays[..., :3].contiguous(), rays[..., 3:6].contiguous())
+    return positions, idx, valid
+
+
+def scene_bounds(scene, views, dataset, device):
+    """slf_bake.py:69-93 including its scannetpp centre (``voxel_c = voxel_min + voxel_max``, not halved: kept, the files depend on it)."""
+    voxel_min, voxel_max = 1000., 0.0
+    for batch in views:
+        positions, _, valid = _hits(scene, batch, device)
+        if not valid.any():
+            continue
+        position = positions[valid]
+        voxel_min = min(voxel_min, position.min())
+        voxel_max = max(voxel_max, position.max())
+    if dataset in ("synthetic", "real"):
+        voxel_min = 1.1 * voxel_min
+        voxel_max = 1.1 * voxel_max
+    else:
+        voxel_c = voxel_min + voxel_max
+        voxel_min, voxel_max = voxel_c + (voxel_min - voxel_c) * 1.1, voxel_c + (voxel_max - voxel_c) * 1.1
+    return torch.as_tensor(voxel_min, dtype=torch.float32), torch.as_tensor(voxel_max, dtype=torch.float32)
+
+
+def visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device):
+    """slf_bake.py:95-114: SpatialHist (res,res,res) f32 [z,y,x]; mask = SpatialHist > 0."""
+    hist = torch.zeros(res_spatial, res_spatial, res_spatial, device=device, dtype=torch.float32)
+    for batch in views:
+        positions, _, valid = _hits(scene, batch, device)
+        if not valid.any():
+            continue
+        voxel_histogram(positions[valid], float(voxel_min), float(voxel_max), res_spatial, hist)
+    return hist
+
+
+def pool_radiance(scene, views, vslf, device):
+    """slf_bake.py:120-138 / slf_refine.py:90-106: scatter every valid primary hit's radiance into its voxel, then average."""
+    vslf = vslf.to(device)
+    for batch in views:
+        positions, _, valid = _hits(scene, batch, device)
+        if not valid.any():
+            continue
+        vslf.scatter_add(positions[valid], batch["rgbs"].to(device=device, dtype=torch.float32)[valid])
+    vslf.radiance = vslf.radiance / vslf.count[..., None].float().clamp_min(1)
+    vslf.refresh()
+    return vslf
+
+
+def bake_slf(scene, views, res_spatial=256, dataset="scannetpp", device="cuda"):
+    """-> the dict slf_bake.py:140-145 saves as vslf.npz: {'mask', 'voxel_min', 'voxel_max', 'weight'}  (tensors on the host)."""
+    views = list(views)
+    device = torch.device(device)
+    voxel_min, voxel_max = scene_bounds(scene, views, dataset, device)
+    hist = visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device)
+    mask = hist > 0
+    vslf = VoxelSLF(mask.cpu(), voxel_min.item(), voxel_max.item())
+    vslf = pool_radiance(scene, views, vslf, device)
+    return {"mask": mask.cpu(), "voxel_min": voxel_min.item(), "voxel_max": voxel_max.item(),
+            "weight": {k: v.cpu() for k, v in vslf.state_dict().items()}}
+
+
+def refine_slf(state_dict, scene, views, device="cuda"):
+    """slf_refine.py:85-108: same grid, radiance pooled anew; returns the updated dict."""
+    vslf = VoxelSLF(state_dict["mask"], state_dict["voxel_min"], state_dict["voxel_max"])
+    vslf = pool_radiance(scene, list(views), vslf, torch.device(device))
+    out = dict(state_dict)
+    out["weight"] = {k: v.cpu() for k, v in vslf.state_dict().items()}
+    return out
+
+
+def extract_emitters(scene, vertices, faces, views, threshold, device="cuda"):
+    """extract_emitter_ldr.py:77-115 (mode 'export'): per-triangle mean of the radiance of the primary hits that landed on it, max over
+    the channels, > threshold -> emitter; returns the dict saved as emitter.pth."""
+    device = torch.device(device)
+    vertices = torch.as_tensor(vertices, dtype=torch.float32); faces = torch.as_tensor(faces).long()
+    n_face = len(faces)
+    triangle_radiance = torch.zeros(n_face, 3, device=device)
+    triangle_count = torch.zeros(n_face, device=device)
+    for batch in views:
+        _, idx, valid = _hits(scene, batch, device)
+        if not valid.any():
+            continue
+        scatter_add_rows(batch["rgbs"].to(device=device, dtype=torch.float32)[valid], idx[valid], triangle_radiance, triangle_count)
+    mean = triangle_radiance / triangle_count.unsqueeze(-1).clamp_min(1)
+    is_emitter = (torch.max(mean, dim=-1)[0] > threshold).cpu()
+    ev = vertices[faces[is_emitter]]
+    area = torch.cross(ev[:, 1] - ev[:, 0], ev[:, 2] - ev[:, 0], dim=-1)
+    return {"is_emitter": is_emitter, "emitter_vertices": ev, "emitter_area": area.norm(dim=-1) / 2.0, "emitter_normal": NF.normalize(area, dim=-1),
+            "emitter_radiance": torch.zeros(n_face, 3)}
