@@ -55,11 +55,12 @@ def build_workload(args, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--views", type=int, default=32, help="cameras on the circle (cfg 3); the K timed steps bake K views evenly spaced among them (--views 1: the same view every step)")
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--scene-seed", type=int, default=1)
     ap.add_argument("--slf-res", type=int, default=256)
@@ -114,8 +115,9 @@ def main():
 
     ev_pairs = []   # (start,end) HIP events around every specular bake launch, on the launch stream
 
-    def step(record_events=False, gather=True):
+    def step(record_events=False, gather=True, view=0):
         """One view: rays -> primary hits (this rank's stripes) -> 7 fused lobe kernels -> scatter -> one all_gather."""
+        c2w = synth.camera(H, W, view % args.views, n_views=args.views)[1]      # the train-view sequence: cameras on a circle (cfg 3)
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         xs, ds = xs[pix_local], ds[pix_local]
         g = bs.primary_hits(scene, xs, ds, pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
@@ -158,16 +160,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(view=(i * args.views) // max(args.warmup, 1) + 1)
     sync()
     t0 = time.perf_counter()
     rays_local = 0
-    for _ in range(args.steps):
-        r, full = step()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-view times, read after the timed region
+    marks[0].record()
+    for i in range(args.steps):
+        r, full = step(view=(i * args.views) // max(args.steps, 1))          # K views evenly spaced over the sequence
         rays_local += r
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    ms_by_view = [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)]
     if rank == 0 and not args.no_roofline and any(l > 0 for l in lobes):
         for _ in range(2):                      # per-launch durations of the dominant kernel: separate, serialised pass (HIP events
             step(record_events=True, gather=False)   # on the launch stream); rank 0 only, hence no collective in this pass
@@ -184,9 +190,9 @@ def main():
         "metric": "bake_shading throughput (shading samples/s: secondary rays traced and shaded)", "value": round(value, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"bake_shading one {W}x{H} view, SPP={spp} per lobe, lobes={lobes} (0=diffuse,1-6=specular), synthetic room "
+        "config": {"workload": f"bake_shading train-view sequence ({args.steps} views evenly spaced among {args.views} cameras on a circle, one view per step), {W}x{H}, SPP={spp} per lobe, lobes={lobes} (0=diffuse,1-6=specular), synthetic room "
                                f"seed={args.scene_seed} {info['n_triangles']} triangles, SLF H={args.slf_res}, Philox uniforms",
-                   "pixels_per_view": H * W, "rays_per_step": int(rays_total / max(args.steps, 1)), "sharding": f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 all_gather",
+                   "pixels_per_view": H * W, "rays_per_step": int(rays_total / max(args.steps, 1)), "ms_by_view": ms_by_view[:32], "sharding": f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 all_gather",
                    "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"]}},
     }
 

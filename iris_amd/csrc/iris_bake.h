@@ -37,14 +37,15 @@ __device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int
 
 struct RayOut { float r0, g0, b0, r1, g1, b1; };
 
-// One (pixel, sample): sample the lobe, trace, shade.  Everything between the uniforms and Le*g stays in registers.
-template <bool SPEC, bool COUNT, int LAYOUT, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
-__device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int s, f3 x, f3 n, f3 w, f3 t, f3 b, uint64_t base,
-                                               uint32_t* lds_stack, TraceStats* ts, uint32_t& n_rays, uint32_t* ovf = nullptr) {
+// One (pixel, sample) in two halves.  sample_lobe: uniforms -> incident direction (+ the GGX weights of the specular lobe);
+// trace_shade: trace it, evaluate the emitter / SLF at the hit, weight.  The tile kernels run the first half in their binning
+// pass and park (wi, g0, g1) in the ray's result slot, so that the traversal pass carries only the origin and those five floats.
+template <bool SPEC>
+__device__ __forceinline__ void sample_lobe(const BakeArgs& a, int64_t p, int s, f3 n, f3 w, f3 t, f3 b, uint64_t base, f3& wi, float& g0, float& g1) {
     float u0, u1;
     if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
     else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
-    f3 wi; float g0 = 1.f, g1 = 0.f;
+    g0 = 1.f; g1 = 0.f;
     if (SPEC) {
         wi = specular_sampler(u0, u1, a.rough, w, n, t, b);
         SpecW sw = specular_weights(wi, w, n, a.rough, false);
@@ -52,6 +53,11 @@ __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int
     } else {
         wi = diffuse_sampler(u0, u1, n, t, b);
     }
+}
+
+template <bool SPEC, bool COUNT, int LAYOUT, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
+__device__ __forceinline__ RayOut trace_shade(const BakeArgs& a, int64_t p, int s, f3 x, f3 wi, float g0, float g1, uint32_t* lds_stack,
+                                              TraceStats* ts, uint32_t& n_rays, uint32_t* ovf = nullptr) {
     // position + RayEpsilon*wi  (bake_shading.py:117, :180)
     f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
     const uint32_t steps0 = COUNT ? ts->nodes + ts->tris : 0;
@@ -79,6 +85,14 @@ __device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int
     if (SPEC) { r.r0 = Le.x * g0; r.g0 = Le.y * g0; r.b0 = Le.z * g0; r.r1 = Le.x * g1; r.g1 = Le.y * g1; r.b1 = Le.z * g1; }
     else { r.r0 = Le.x; r.g0 = Le.y; r.b0 = Le.z; r.r1 = r.g1 = r.b1 = 0.f; }
     return r;
+}
+
+template <bool SPEC, bool COUNT, int LAYOUT, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
+__device__ __forceinline__ RayOut shade_sample(const BakeArgs& a, int64_t p, int s, f3 x, f3 n, f3 w, f3 t, f3 b, uint64_t base,
+                                               uint32_t* lds_stack, TraceStats* ts, uint32_t& n_rays, uint32_t* ovf = nullptr) {
+    f3 wi; float g0, g1;
+    sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
+    return trace_shade<SPEC, COUNT, LAYOUT, LDS_DEPTH, GLOBAL_OVF>(a, p, s, x, wi, g0, g1, lds_stack, ts, n_rays, ovf);
 }
 
 template <bool COUNT>
@@ -214,10 +228,12 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
             const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
             f3 t, b;
             normal_space(n, t, b);
-            float u0, u1;
-            if (a.u2) { const float* up = a.u2 + (p * spp + s) * 2; u0 = up[0]; u1 = up[1]; }
-            else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
-            const f3 wi = SPEC ? specular_sampler(u0, u1, a.rough, w, n, t, b) : diffuse_sampler(u0, u1, n, t, b);
+            f3 wi; float g0, g1;
+            sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
+            float4* q = res + (size_t)r * NC;          // parked in the ray's result slot until phase C replaces it with the result;
+                                                       // read back by another wave of this workgroup after the barriers below
+            q[0] = make_float4(wi.x, wi.y, wi.z, g0);
+            if (SPEC) q[1] = make_float4(g1, 0.f, 0.f, 0.f);
             const uint32_t key = dir_bin(wi);
             s_keys[r] = (uint8_t)key;
             atomicAdd(&s_hist[key], 1u);
@@ -250,21 +266,19 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
                 const int r = s_sorted[i];
                 const int pl = r / spp, s = r - pl * spp;
                 const int64_t p = p0 + pl;
-                const f3 x = ld3(a.pos + p * 3), n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
-                const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
-                f3 t, b;
-                normal_space(n, t, b);
-                RayOut o = shade_sample<SPEC, COUNT, LAYOUT, kTileStack, true>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays, ovf);
+                const f3 x = ld3(a.pos + p * 3);
                 float4* q = res + (size_t)r * NC;
+                const float4 qa = q[0];
+                const float g1 = SPEC ? q[1].x : 0.f;
+                RayOut o = trace_shade<SPEC, COUNT, LAYOUT, kTileStack, true>(a, p, s, x, mk3(qa.x, qa.y, qa.z), qa.w, g1, s_stack + tid, &ts, n_rays, ovf);
                 q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
                 if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
             }
         }
-        // results were written by other waves of this workgroup, possibly to lines this CU's L1 still holds from the
-        // previous tile: release, barrier, acquire (agent scope) before reading them back
-        __threadfence();
+        // results were written by other waves of THIS workgroup: __syncthreads() orders global memory at workgroup scope (all waves
+        // of a workgroup share their CU's write-through L1, so no invalidate / write-back is needed; an agent-scope __threadfence()
+        // here would flush the L1 -- including the hot BVH nodes -- once per tile and was measured 9 % slower)
         __syncthreads();
-        __threadfence();
 
         // ---- phase D: per-pixel mean in the fixed order of v1 (lane-strided partial sums, xor butterfly)
         const int n_groups = (np + ppw - 1) / ppw;
@@ -335,9 +349,11 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
         const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
         f3 t, b;
         normal_space(n, t, b);
-        float u0, u1;
-        philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
-        const f3 wi = SPEC ? specular_sampler(u0, u1, a.rough, w, n, t, b) : diffuse_sampler(u0, u1, n, t, b);
+        f3 wi; float g0, g1;
+        sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
+        float4* q = res + (size_t)r * NC;
+        q[0] = make_float4(wi.x, wi.y, wi.z, g0);
+        if (SPEC) q[1] = make_float4(g1, 0.f, 0.f, 0.f);
         const uint32_t key = dir_bin(wi);
         s_keys[r] = (uint8_t)key;
         atomicAdd(&s_hist[key], 1u);
@@ -368,19 +384,16 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
             const int r = s_sorted[i];
             const int pl = r / spp, s = r - pl * spp;
             const int64_t p = p0 + pl;
-            const f3 x = ld3(a.pos + p * 3), n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
-            const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
-            f3 t, b;
-            normal_space(n, t, b);
-            RayOut o = shade_sample<SPEC, false, LAYOUT, TILE_STACK, true>(a, p, s, x, n, w, t, b, base, s_stack + tid, &ts, n_rays, ovf);
+            const f3 x = ld3(a.pos + p * 3);
             float4* q = res + (size_t)r * NC;
+            const float4 qa = q[0];
+            const float g1 = SPEC ? q[1].x : 0.f;
+            RayOut o = trace_shade<SPEC, false, LAYOUT, TILE_STACK, true>(a, p, s, x, mk3(qa.x, qa.y, qa.z), qa.w, g1, s_stack + tid, &ts, n_rays, ovf);
             q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
             if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
         }
     }
-    __threadfence();
-    __syncthreads();
-    __threadfence();
+    __syncthreads();   // workgroup-scope ordering of the result slots, see bake_tile_kernel
     // ---- phase D
     const int n_groups = (np + ppw - 1) / ppw;
     for (int g = wave; g < n_groups; g += kBlock / 64) {

@@ -473,6 +473,28 @@ def test_bake_edge_cases(dev, room_setup):
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
 
 
+def test_view_kernel_many_tiles_per_workgroup(dev, room_setup):
+    """640x480 pixels x 3 lobes: every persistent workgroup of iris_bake_view takes several tiles, so result slots are reused between
+    tiles and between lobes; bits must equal the per-lobe launches (themselves bit-exact against the oracle at this size)."""
+    from tools import synth
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.dataset import real_ldr
+    s = room_setup
+    H, W = 480, 640
+    K, c2w = synth.camera(H, W, 5)
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+    g = bs.primary_hits(s["sc"], xs, ds, image_width=W)
+    res = bs.bake_lobes(s["sc"], s["em"], g["position"], g["normal"], g["wo"], [None, 0.216, 1.0], [64, 32, 64], seed=4, stream_ids=[0, 2, 6], pix_id=g["pix_id"])
+    for _ in range(2):                                                   # and again: slots now hold the previous launch's values
+        res2 = bs.bake_lobes(s["sc"], s["em"], g["position"], g["normal"], g["wo"], [None, 0.216, 1.0], [64, 32, 64], seed=4, stream_ids=[0, 2, 6], pix_id=g["pix_id"])
+        assert torch.equal(res[0], res2[0]) and torch.equal(res[2][1], res2[2][1])
+    assert torch.equal(res[0], bs.bake_diffuse(s["sc"], s["em"], g["position"], g["normal"], 64, seed=4, stream_id=0, pix_id=g["pix_id"]))
+    a, b = bs.bake_specular(s["sc"], s["em"], g["position"], g["normal"], g["wo"], 0.216, 32, seed=4, stream_id=2, pix_id=g["pix_id"])
+    assert torch.equal(res[1][0], a) and torch.equal(res[1][1], b)
+    a, b = bs.bake_specular(s["sc"], s["em"], g["position"], g["normal"], g["wo"], 1.0, 64, seed=4, stream_id=6, pix_id=g["pix_id"], variant=1)
+    assert torch.equal(res[2][0], a) and torch.equal(res[2][1], b)         # variant 1 = pixel-per-wave kernel: no result slots at all
+
+
 def test_view_kernel_equals_per_lobe_launches(dev, room_setup):
     """iris_bake_view (all lobes of a view behind one launch / one tile queue) gives the bits of the per-lobe entry points,
     with the reference's per-lobe spp (256 / 64 / 128...) and with a ragged pixel count."""
