@@ -177,171 +177,39 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     return m;
 }
 
-#ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernel is compiled for (= workgroups per CU)
+#ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU)
 #define IRIS_TILE_WAVES 6
 #endif
-#ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernel; deeper entries go to the workgroup's slab in the workspace
+#ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
 #define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
 #endif
-template <bool SPEC, bool COUNT, int LAYOUT>
-__global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
-    // LDS: sorted ray list (16 KiB) + traversal stacks (24 KiB).  The stack region doubles as the sort's key / histogram
-    // storage: the two uses are separated by workgroup barriers.
-    constexpr int kTileStack = IRIS_TILE_STACK;  // 16384 B ray list + kTileStack KiB stacks + 8 B must fit 160 KiB / IRIS_TILE_WAVES
-    __shared__ uint16_t s_sorted[kTileRays];
-    __shared__ uint32_t s_stack[kTileStack * kBlock];
-    __shared__ int s_tile, s_chunk;
-    static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
-    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
-    uint32_t* s_hist = s_stack + kTileRays / 4;
-    uint32_t* s_cur = s_hist + 256;
 
+// One tile (<= kTileRays rays = tile_px consecutive valid pixels x spp) of one lobe, by one 256-thread workgroup.
+//   LDS: s_sorted (16 KiB ray list) + s_stack (TILE_STACK KiB traversal stacks; doubles as the sort's key / histogram storage, the
+//   two uses are separated by workgroup barriers) + *s_chunk (cursor into the sorted list).
+//   res: the workgroup's slab of per-ray slots (NC float4 each) in the workspace.  Slot life: phase A parks the sampled direction
+//   (q0 = wi) and the GGX weights (q1 = g1, g0); phase C replaces q0 by the hit (u, v, leaf slot); phase D shades and sums.
+//   The slots are only ever exchanged between waves of THIS workgroup, so __syncthreads() orders them (the waves of a workgroup
+//   share their CU's write-through L1; an agent-scope __threadfence() here flushes that L1 -- including the hot upper BVH levels --
+//   once per tile and was measured 9 % slower per fence pair).
+template <bool SPEC, bool COUNT, int LAYOUT, int TILE_STACK>
+__device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
+                                          uint32_t* ovf, TraceStats& ts, uint32_t& n_rays) {
+    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
+    uint32_t* s_hist = s_stack + kTileRays / 4;     // zeroed by the caller before the barrier that published the tile index
+    uint32_t* s_cur = s_hist + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
     constexpr int NC = SPEC ? 2 : 1;  // float4 per ray
-    float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
-    uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock + tid;
-    const int64_t n_tiles = (a.P + a.tile_px - 1) / a.tile_px;
     int lpp, ppw, rounds;
     reduce_geometry(spp, lpp, ppw, rounds);
     const int sub = lane / lpp, sl = lane - sub * lpp;
     const float inv_spp = 1.0f / (float)spp;
-    TraceStats ts;
-    uint32_t n_rays = 0;
-
-    for (;;) {
-        __syncthreads();  // previous tile fully done with LDS
-        if (tid == 0) { s_tile = (int)atomicAdd(a.tile_counter, 1u); s_chunk = 0; }
-        s_hist[tid] = 0;  // kBlock == 256 bins
-        __syncthreads();
-        const int64_t tile = s_tile;
-        if (tile >= n_tiles) break;
-        const int64_t p0 = tile * a.tile_px;
-        const int np = (int)min((int64_t)a.tile_px, a.P - p0);
-        const int nr = np * spp;
-
-        // ---- phase A: direction bin of every ray of the tile, histogram
-        for (int r = tid; r < nr; r += kBlock) {
-            const int pl = r / spp, s = r - pl * spp;
-            const int64_t p = p0 + pl;
-            const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
-            const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
-            f3 t, b;
-            normal_space(n, t, b);
-            f3 wi; float g0, g1;
-            sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
-            float4* q = res + (size_t)r * NC;          // parked in the ray's result slot until phase C replaces it with the result;
-                                                       // read back by another wave of this workgroup after the barriers below
-            q[0] = make_float4(wi.x, wi.y, wi.z, g0);
-            if (SPEC) q[1] = make_float4(g1, 0.f, 0.f, 0.f);
-            const uint32_t key = dir_bin(wi);
-            s_keys[r] = (uint8_t)key;
-            atomicAdd(&s_hist[key], 1u);
-        }
-        __syncthreads();
-        // ---- exclusive prefix over the 256 bins (wave 0: 4 bins per lane)
-        if (wave == 0) {
-            uint32_t c0 = s_hist[lane * 4], c1 = s_hist[lane * 4 + 1], c2 = s_hist[lane * 4 + 2], c3 = s_hist[lane * 4 + 3];
-            uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
-            for (int m = 1; m < 64; m <<= 1) { uint32_t v = __shfl_up(inc, m); if (lane >= m) inc += v; }
-            uint32_t ex = inc - tot;
-            s_cur[lane * 4] = ex; s_cur[lane * 4 + 1] = ex + c0; s_cur[lane * 4 + 2] = ex + c0 + c1; s_cur[lane * 4 + 3] = ex + c0 + c1 + c2;
-        }
-        __syncthreads();
-        // ---- phase B: scatter ray ids into bin order (order inside a bin is irrelevant: results go to per-ray slots)
-        for (int r = tid; r < nr; r += kBlock) {
-            const uint32_t pos = atomicAdd(&s_cur[s_keys[r]], 1u);
-            s_sorted[pos] = (uint16_t)r;
-        }
-        __syncthreads();  // keys / histogram dead from here on: the region becomes the traversal stacks
-
-        // ---- phase C: trace in sorted order, 64 consecutive sorted rays per wave-iteration
-        for (;;) {
-            int c = 0;
-            if (lane == 0) c = atomicAdd(&s_chunk, 1);
-            c = __builtin_amdgcn_readfirstlane(c);
-            if (c * 64 >= nr) break;
-            const int i = c * 64 + lane;
-            if (i < nr) {
-                const int r = s_sorted[i];
-                const int pl = r / spp, s = r - pl * spp;
-                const int64_t p = p0 + pl;
-                const f3 x = ld3(a.pos + p * 3);
-                float4* q = res + (size_t)r * NC;
-                const float4 qa = q[0];
-                const float g1 = SPEC ? q[1].x : 0.f;
-                RayOut o = trace_shade<SPEC, COUNT, LAYOUT, kTileStack, true>(a, p, s, x, mk3(qa.x, qa.y, qa.z), qa.w, g1, s_stack + tid, &ts, n_rays, ovf);
-                q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
-                if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
-            }
-        }
-        // results were written by other waves of THIS workgroup: __syncthreads() orders global memory at workgroup scope (all waves
-        // of a workgroup share their CU's write-through L1, so no invalidate / write-back is needed; an agent-scope __threadfence()
-        // here would flush the L1 -- including the hot BVH nodes -- once per tile and was measured 9 % slower)
-        __syncthreads();
-
-        // ---- phase D: per-pixel mean in the fixed order of v1 (lane-strided partial sums, xor butterfly)
-        const int n_groups = (np + ppw - 1) / ppw;
-        for (int g = wave; g < n_groups; g += kBlock / 64) {
-            const int pl = g * ppw + sub;
-            const bool pvalid = pl < np;
-            float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
-            for (int rr = 0; rr < rounds; ++rr) {
-                const int s = rr * 64 + sl;
-                if (pvalid && s < spp) {
-                    const float4* q = res + (size_t)(pl * spp + s) * NC;
-                    const float4 qa = q[0];
-                    a0x += qa.x; a0y += qa.y; a0z += qa.z;
-                    if (SPEC) { const float4 qb = q[1]; a1x += qa.w; a1y += qb.x; a1z += qb.y; }
-                }
-            }
-            for (int m = 1; m < lpp; m <<= 1) {
-                a0x += __shfl_xor(a0x, m); a0y += __shfl_xor(a0y, m); a0z += __shfl_xor(a0z, m);
-                if (SPEC) { a1x += __shfl_xor(a1x, m); a1y += __shfl_xor(a1y, m); a1z += __shfl_xor(a1z, m); }
-            }
-            if (pvalid && sl == 0) {
-                const int64_t p = p0 + pl;
-                st3(a.out0 + p * 3, mk3(a0x * inv_spp, a0y * inv_spp, a0z * inv_spp));
-                if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
-            }
-        }
-    }
-    flush_stats<COUNT>(a, ts, n_rays);
-}
-
-// ------------------------------------------------------------------------------------------------------- view kernel
-// bake_view_kernel: ALL lobes of a view (diffuse + the specular roughness levels, bake_shading.py:93-204) behind ONE persistent
-// launch and ONE tile queue.  Per tile it is exactly bake_tile_kernel (same phases, same bits); what it removes is the idle
-// time at the end of every per-lobe launch, when the last ~3 ms tiles run on a few CUs -- which matters once a view is sharded
-// over 8 GPUs and a rank has only ~3 tiles per resident workgroup per lobe.
-constexpr int kMaxLobes = 8;
-struct ViewLobe { float rough; int spp; uint32_t stream_id; int spec; int tile_px; int pad_; long long tile_begin; float* out0; float* out1; };
-struct ViewArgs {
-    BakeArgs base;          // scene / tables / pixel tensors / seed / scratch / tile_counter (per-lobe fields unused)
-    int n_lobes;
-    long long n_tiles;      // over all lobes
-    ViewLobe lobe[kMaxLobes];
-};
-
-template <bool SPEC, int LAYOUT, int TILE_STACK>
-__device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
-                                          uint32_t* ovf) {
-    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
-    uint32_t* s_hist = s_stack + kTileRays / 4;
-    uint32_t* s_cur = s_hist + 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int spp = a.spp;
-    constexpr int NC = SPEC ? 2 : 1;
-    int lpp, ppw, rounds;
-    reduce_geometry(spp, lpp, ppw, rounds);
-    const int sub = lane / lpp, sl = lane - sub * lpp;
-    const float inv_spp = 1.0f / (float)spp;
-    TraceStats ts;
-    uint32_t n_rays = 0;
     const int64_t p0 = tile * a.tile_px;
     const int np = (int)min((int64_t)a.tile_px, a.P - p0);
     const int nr = np * spp;
-    // ---- phase A
+
+    // ---- phase A: sample every ray of the tile (uniforms -> direction + GGX weights), park it, histogram of the direction bins
     for (int r = tid; r < nr; r += kBlock) {
         const int pl = r / spp, s = r - pl * spp;
         const int64_t p = p0 + pl;
@@ -352,13 +220,14 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
         f3 wi; float g0, g1;
         sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
         float4* q = res + (size_t)r * NC;
-        q[0] = make_float4(wi.x, wi.y, wi.z, g0);
-        if (SPEC) q[1] = make_float4(g1, 0.f, 0.f, 0.f);
+        q[0] = make_float4(wi.x, wi.y, wi.z, 0.f);
+        if (SPEC) q[1] = make_float4(g1, g0, 0.f, 0.f);
         const uint32_t key = dir_bin(wi);
         s_keys[r] = (uint8_t)key;
         atomicAdd(&s_hist[key], 1u);
     }
     __syncthreads();
+    // ---- exclusive prefix over the 256 bins (wave 0: 4 bins per lane)
     if (wave == 0) {
         uint32_t c0 = s_hist[lane * 4], c1 = s_hist[lane * 4 + 1], c2 = s_hist[lane * 4 + 2], c3 = s_hist[lane * 4 + 3];
         uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
@@ -367,34 +236,41 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
         s_cur[lane * 4] = ex; s_cur[lane * 4 + 1] = ex + c0; s_cur[lane * 4 + 2] = ex + c0 + c1; s_cur[lane * 4 + 3] = ex + c0 + c1 + c2;
     }
     __syncthreads();
-    // ---- phase B
+    // ---- phase B: scatter ray ids into bin order (order inside a bin is irrelevant: results go to per-ray slots)
     for (int r = tid; r < nr; r += kBlock) {
         const uint32_t pos = atomicAdd(&s_cur[s_keys[r]], 1u);
         s_sorted[pos] = (uint16_t)r;
     }
-    __syncthreads();
-    // ---- phase C
-    for (;;) {
-        int c = 0;
-        if (lane == 0) c = atomicAdd(s_chunk, 1);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c * 64 >= nr) break;
-        const int i = c * 64 + lane;
-        if (i < nr) {
-            const int r = s_sorted[i];
-            const int pl = r / spp, s = r - pl * spp;
-            const int64_t p = p0 + pl;
-            const f3 x = ld3(a.pos + p * 3);
-            float4* q = res + (size_t)r * NC;
-            const float4 qa = q[0];
-            const float g1 = SPEC ? q[1].x : 0.f;
-            RayOut o = trace_shade<SPEC, false, LAYOUT, TILE_STACK, true>(a, p, s, x, mk3(qa.x, qa.y, qa.z), qa.w, g1, s_stack + tid, &ts, n_rays, ovf);
-            q[0] = make_float4(o.r0, o.g0, o.b0, SPEC ? o.r1 : 0.f);
-            if (SPEC) q[1] = make_float4(o.g1, o.b1, 0.f, 0.f);
-        }
+    __syncthreads();  // keys / histogram dead from here on: the region becomes the traversal stacks
+
+    // ---- phase C: persistent-lane traversal of the sorted list (trace_stream): idle lanes claim the next rays together
+    {
+        int my_r = 0;
+        auto fetch = [&](f3& o, f3& d) -> bool {
+            const unsigned long long m = __ballot(1);
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_chunk, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (i >= nr) return false;
+            my_r = s_sorted[i];
+            const int64_t p = p0 + my_r / spp;
+            o = ld3(a.pos + p * 3);                       // raw: the pixel's position; prepare() offsets it
+            const float4 qa = res[(size_t)my_r * NC];
+            d = mk3(qa.x, qa.y, qa.z);
+            if (COUNT) n_rays++;
+            return true;
+        };
+        // position + RayEpsilon*wi (bake_shading.py:117, :180)
+        auto prepare = [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); };
+        auto retire = [&](const Hit& h) { res[(size_t)my_r * NC] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f); };
+        trace_stream<LAYOUT, COUNT, TILE_STACK, true>(a.sc, s_stack + tid, ovf, &ts, fetch, prepare, retire);
     }
-    __syncthreads();   // workgroup-scope ordering of the result slots, see bake_tile_kernel
-    // ---- phase D
+    __syncthreads();
+
+    // ---- phase D: shade every sample (hit -> p_next -> eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0),
+    // bake_shading.py:121-122, :184-185 -> Le * g) and take the per-pixel mean in the fixed order of the pixel-per-wave kernel
+    // (lane-strided partial sums, xor butterfly)
     const int n_groups = (np + ppw - 1) / ppw;
     for (int g = wave; g < n_groups; g += kBlock / 64) {
         const int pl = g * ppw + sub;
@@ -405,8 +281,23 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
             if (pvalid && s < spp) {
                 const float4* q = res + (size_t)(pl * spp + s) * NC;
                 const float4 qa = q[0];
-                a0x += qa.x; a0y += qa.y; a0z += qa.z;
-                if (SPEC) { const float4 qb = q[1]; a1x += qa.w; a1y += qb.x; a1z += qb.y; }
+                Hit h; h.u = qa.x; h.v = qa.y; h.slot = __float_as_int(qa.z); h.t = 0.f; h.id = 0;
+                f3 pn = mk3(0.f, 0.f, 0.f);
+                int64_t tri = -1;
+                if (h.slot >= 0) {
+                    const float4* tr = a.sc.tris + (int64_t)h.slot * 3;
+                    const float4 ta = tr[0], tb = tr[1], tc = tr[2];
+                    pn = hit_position(h, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x));
+                    tri = __float_as_int(tc.y);
+                }
+                if (a.tri_next) a.tri_next[(p0 + pl) * spp + s] = tri;
+                float epdf; bool vn;
+                const f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
+                if (SPEC) {
+                    const float4 qb = q[1];
+                    a0x += Le.x * qb.y; a0y += Le.y * qb.y; a0z += Le.z * qb.y;
+                    a1x += Le.x * qb.x; a1y += Le.y * qb.x; a1z += Le.z * qb.x;
+                } else { a0x += Le.x; a0y += Le.y; a0z += Le.z; }
             }
         }
         for (int m = 1; m < lpp; m <<= 1) {
@@ -421,8 +312,47 @@ __device__ __forceinline__ void view_tile(const BakeArgs& a, long long tile, flo
     }
 }
 
-// 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B of LDS per workgroup, 6 workgroups per CU); like the tile
-// kernel, stack entries beyond the LDS part go to the workgroup's slab in the workspace, so the kernel uses no private scratch.
+template <bool SPEC, bool COUNT, int LAYOUT>
+__global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
+    constexpr int kTileStack = IRIS_TILE_STACK;  // 16384 B ray list + kTileStack KiB stacks + 8 B must fit 160 KiB / IRIS_TILE_WAVES
+    __shared__ uint16_t s_sorted[kTileRays];
+    __shared__ uint32_t s_stack[kTileStack * kBlock];
+    __shared__ int s_tile, s_chunk;
+    static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
+    const int tid = threadIdx.x;
+    constexpr int NC = SPEC ? 2 : 1;
+    float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
+    uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock + tid;
+    const int64_t n_tiles = (a.P + a.tile_px - 1) / a.tile_px;
+    TraceStats ts;
+    uint32_t n_rays = 0;
+    for (;;) {
+        __syncthreads();  // previous tile fully done with LDS
+        if (tid == 0) { s_tile = (int)atomicAdd(a.tile_counter, 1u); s_chunk = 0; }
+        (s_stack + kTileRays / 4)[tid] = 0;  // histogram: kBlock == 256 bins
+        __syncthreads();
+        const int64_t tile = s_tile;
+        if (tile >= n_tiles) break;
+        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
+    }
+    flush_stats<COUNT>(a, ts, n_rays);
+}
+
+// ------------------------------------------------------------------------------------------------------- view kernel
+// bake_view_kernel: ALL lobes of a view (diffuse + the specular roughness levels, bake_shading.py:93-204) behind ONE persistent
+// launch and ONE tile queue.  Per tile it is exactly bake_tile_kernel (tile_body, same bits); what it removes is the idle
+// time at the end of every per-lobe launch, when the last ~3 ms tiles run on a few CUs -- which matters once a view is sharded
+// over 8 GPUs and a rank has only ~3 tiles per resident workgroup per lobe.
+constexpr int kMaxLobes = 8;
+struct ViewLobe { float rough; int spp; uint32_t stream_id; int spec; int tile_px; int pad_; long long tile_begin; float* out0; float* out1; };
+struct ViewArgs {
+    BakeArgs base;          // scene / tables / pixel tensors / seed / scratch / tile_counter (per-lobe fields unused)
+    int n_lobes;
+    long long n_tiles;      // over all lobes
+    ViewLobe lobe[kMaxLobes];
+};
+
+// Same occupancy as the tile kernel: 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B of LDS per workgroup).
 #ifndef IRIS_VIEW_WAVES
 #define IRIS_VIEW_WAVES 6
 #endif
@@ -451,8 +381,9 @@ __global__ __launch_bounds__(kBlock, IRIS_VIEW_WAVES) void bake_view_kernel(View
         BakeArgs a = v.base;
         a.spp = v.lobe[l].spp; a.rough = v.lobe[l].rough; a.stream_id = v.lobe[l].stream_id; a.tile_px = v.lobe[l].tile_px;
         a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr;
-        if (v.lobe[l].spec) view_tile<true, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf);
-        else view_tile<false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf);
+        TraceStats ts; uint32_t n_rays = 0;   // unused (COUNT = false)
+        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
+        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
     }
 }
 

@@ -109,94 +109,208 @@ constexpr int kPhaseMin = 16;
 constexpr int kLayoutF32 = 1, kLayoutQ8 = 3;
 __device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xffu); }
 
-template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
-__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
-    Hit h; h.t = INFINITY; h.u = 0.f; h.v = 0.f; h.slot = -1; h.id = 0x7fffffff;
-    const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
-    const float nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
-    const bool px = ix >= 0.f, py = iy >= 0.f, pz = iz >= 0.f;
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
-    uint32_t cur = 0;  // root
-    int k = 0;         // triangles of the current leaf already tested
-    int max_sp = 0;
-    const int kPhaseMinRt = sc.phase_min;
-    for (;;) {
-        // ---------------- node phase
-        for (;;) {
-            const bool at_node = cur != kEmptyRef && !(cur & kLeafBit);
-            const int n_node = __popcll(__ballot(at_node));
-            if (n_node == 0) break;
-            if (n_node < kPhaseMinRt && __popcll(__ballot(cur != kEmptyRef && (cur & kLeafBit))) >= kPhaseMinRt) break;
-            if (at_node) {
-                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
-                float k0, k1, k2, k3;
-                uint32_t r0, r1, r2, r3;
-                if (LAYOUT == kLayoutQ8) {
-                    const uint4* n = reinterpret_cast<const uint4*>(sc.nodes) + (int64_t)cur * 4;
-                    const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
-                    r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
-                    // per-axis: t(q) = q * (2^e * idir) + (origin * idir - o * idir)
-                    const float ax = __uint_as_float((hd.w & 0xffu) << 23) * ix, ay = __uint_as_float(((hd.w >> 8) & 0xffu) << 23) * iy,
-                                az = __uint_as_float(((hd.w >> 16) & 0xffu) << 23) * iz;
-                    const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
-                    const uint32_t nxq = px ? q1.x : q1.w, fxq = px ? q1.w : q1.x;
-                    const uint32_t nyq = py ? q1.y : q2.x, fyq = py ? q2.x : q1.y;
-                    const uint32_t nzq = pz ? q1.z : q2.y, fzq = pz ? q2.y : q1.z;
+// Per-lane traversal state shared by the two drivers below (kept in registers; the struct is scalar-replaced).
+struct RayState {
+    f3 o, d;
+    float ix, iy, iz, nx, ny, nz;   // 1/d and -o/d
+    bool px, py, pz;                // direction signs
+    Hit h;
+    uint32_t cur;                   // node / leaf reference, kEmptyRef = no work
+    int k;                          // triangles of the current leaf already tested
+};
+__device__ __forceinline__ void ray_begin(RayState& r, f3 o, f3 d) {
+    r.o = o; r.d = d;
+    r.h.t = INFINITY; r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1; r.h.id = 0x7fffffff;
+    r.ix = safe_rcp_dir(d.x); r.iy = safe_rcp_dir(d.y); r.iz = safe_rcp_dir(d.z);
+    r.nx = -(o.x * r.ix); r.ny = -(o.y * r.iy); r.nz = -(o.z * r.iz);
+    r.px = r.ix >= 0.f; r.py = r.iy >= 0.f; r.pz = r.iz >= 0.f;
+    r.cur = 0; r.k = 0;
+}
+
+// One internal-node visit of the lanes that are at a node: 4 slab tests, 5-comparator sorting network, near child first.
+template <int LAYOUT, class STACK>
+__device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK& st) {
+    float k0, k1, k2, k3;
+    uint32_t r0, r1, r2, r3;
+    const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
+    const bool px = r.px, py = r.py, pz = r.pz;
+    if (LAYOUT == kLayoutQ8) {
+        const uint4* n = reinterpret_cast<const uint4*>(sc.nodes) + (int64_t)r.cur * 4;
+        const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
+        r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
+        // per-axis: t(q) = q * (2^e * idir) + (origin * idir - o * idir)
+        const float ax = __uint_as_float((hd.w & 0xffu) << 23) * ix, ay = __uint_as_float(((hd.w >> 8) & 0xffu) << 23) * iy,
+                    az = __uint_as_float(((hd.w >> 16) & 0xffu) << 23) * iz;
+        const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
+        const uint32_t nxq = px ? q1.x : q1.w, fxq = px ? q1.w : q1.x;
+        const uint32_t nyq = py ? q1.y : q2.x, fyq = py ? q2.x : q1.y;
+        const uint32_t nzq = pz ? q1.z : q2.y, fzq = pz ? q2.y : q1.z;
 #define IRIS_SLABQ(K, C)                                                                                                          \
     {                                                                                                                             \
         float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), ax, bx), fmaf(ubyte(nyq, C), ay, by)), fmaxf(fmaf(ubyte(nzq, C), az, bz), 0.f)); \
-        float tf = fminf(fminf(fmaf(ubyte(fxq, C), ax, bx), fmaf(ubyte(fyq, C), ay, by)), fminf(fmaf(ubyte(fzq, C), az, bz), h.t)); \
+        float tf = fminf(fminf(fmaf(ubyte(fxq, C), ax, bx), fmaf(ubyte(fyq, C), ay, by)), fminf(fmaf(ubyte(fzq, C), az, bz), r.h.t)); \
         K = tn <= tf ? tn : INFINITY;                                                                                             \
     }
-                    IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
+        IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
 #undef IRIS_SLABQ
-                    // NB: hipcc sinks the child-reference load (n[3]) behind the hit test; forcing it up front with the other
-                    // loads was measured 8 % SLOWER (the vector-memory pipe is the bottleneck, and nodes without a hit skip it)
-                } else {
-                const float4* n = sc.nodes + (int64_t)cur * 8;
-                const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
-                const float4 rf = n[6];
-                r0 = __float_as_uint(rf.x); r1 = __float_as_uint(rf.y); r2 = __float_as_uint(rf.z); r3 = __float_as_uint(rf.w);
+        // NB: hipcc sinks the child-reference load (n[3]) behind the hit test; forcing it up front with the other
+        // loads was measured 8 % SLOWER (nodes without a hit skip it)
+    } else {
+        const float4* n = sc.nodes + (int64_t)r.cur * 8;
+        const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
+        const float4 rf = n[6];
+        r0 = __float_as_uint(rf.x); r1 = __float_as_uint(rf.y); r2 = __float_as_uint(rf.z); r3 = __float_as_uint(rf.w);
 #define IRIS_SLAB(K, C)                                                                                               \
     {                                                                                                                 \
         float tn = fmaxf(fmaxf(fmaf(px ? lox.C : hix.C, ix, nx), fmaf(py ? loy.C : hiy.C, iy, ny)),                   \
                          fmaxf(fmaf(pz ? loz.C : hiz.C, iz, nz), 0.f));                                               \
         float tf = fminf(fminf(fmaf(px ? hix.C : lox.C, ix, nx), fmaf(py ? hiy.C : loy.C, iy, ny)),                   \
-                         fminf(fmaf(pz ? hiz.C : loz.C, iz, nz), h.t));                                               \
+                         fminf(fmaf(pz ? hiz.C : loz.C, iz, nz), r.h.t));                                             \
         K = tn <= tf ? tn : INFINITY;                                                                                 \
     }
-                IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
+        IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
 #undef IRIS_SLAB
-                }
-                IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
-                if (k0 < INFINITY) {
-                    cur = r0;
-                    if (k3 < INFINITY) st.push(r3);
-                    if (k2 < INFINITY) st.push(r2);
-                    if (k1 < INFINITY) st.push(r1);
-                    if (COUNT) max_sp = max(max_sp, st.sp);
-                } else {
-                    cur = st.sp > 0 ? st.pop() : kEmptyRef;
-                }
+    }
+    IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
+    if (k0 < INFINITY) {
+        r.cur = r0;
+        if (k3 < INFINITY) st.push(r3);
+        if (k2 < INFINITY) st.push(r2);
+        if (k1 < INFINITY) st.push(r1);
+    } else {
+        r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+    }
+}
+// One triangle of the current leaf.
+template <class STACK>
+__device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, STACK& st) {
+    const int start = (int)((r.cur & 0x7fffffffu) >> 3), cnt = (int)(r.cur & 7u);
+    tri_test(sc, start + r.k, r.o, r.d, r.h);
+    if (++r.k >= cnt) { r.k = 0; r.cur = st.sp > 0 ? st.pop() : kEmptyRef; }
+}
+
+// One ray per lane, run to completion (primary rays, the path-tracing stages, the pixel-per-wave bake kernel).
+template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
+__device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
+    RayState r;
+    ray_begin(r, o, d);
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
+    int max_sp = 0;
+    const int kPhaseMinRt = sc.phase_min;
+    for (;;) {
+        // ---------------- node phase
+        for (;;) {
+            const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
+            const int n_node = __popcll(__ballot(at_node));
+            if (n_node == 0) break;
+            if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
+            if (at_node) {
+                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
+                node_step<LAYOUT>(sc, r, st);
+                if (COUNT) max_sp = max(max_sp, st.sp);
             }
         }
         // ---------------- leaf phase (one triangle per iteration)
         for (;;) {
-            const bool at_leaf = cur != kEmptyRef && (cur & kLeafBit);
+            const bool at_leaf = r.cur != kEmptyRef && (r.cur & kLeafBit);
             const int n_leaf = __popcll(__ballot(at_leaf));
             if (n_leaf == 0) break;
-            if (n_leaf < kPhaseMinRt && __popcll(__ballot(cur != kEmptyRef && !(cur & kLeafBit))) >= kPhaseMinRt) break;
+            if (n_leaf < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && !(r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (at_leaf) {
                 if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
-                const int start = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
-                tri_test(sc, start + k, o, d, h);
-                if (++k >= cnt) { k = 0; cur = st.sp > 0 ? st.pop() : kEmptyRef; }
+                leaf_step(sc, r, st);
             }
         }
-        if (__ballot(cur != kEmptyRef) == 0) break;
+        if (__ballot(r.cur != kEmptyRef) == 0) break;
     }
     if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; }
-    return h;
+    return r.h;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Persistent-lane traversal ("dynamic fetch"): a lane whose ray is finished does not wait for the slowest ray of its wave;
+// once kRefillMin lanes are idle they retire their hits and fetch new rays together.  Same node / leaf steps and phase
+// scheduling as trace_bvh4, so per-ray results are identical; only which rays share a wave changes.
+//   fetch(o, d)  -> bool : called by the idle lanes together: claim a ray and ISSUE the loads of its raw data into o / d without
+//                          using them (they complete behind one step of the other lanes); false = no ray left
+//   prepare(o, d)        : one round later, turn the raw data into origin / direction (first use of the loaded values)
+//   retire(h)            : called by a lane whose ray is complete, before it fetches again / at the end
+// Measured on the 7-lobe bake: threshold 16: -1 %, 32: +4 %, 48: +7 %, 56: +4 %, 64 (= no refill): -4 %.
+// -------------------------------------------------------------------------------------------------------
+#ifndef IRIS_REFILL_MIN
+#define IRIS_REFILL_MIN 48
+#endif
+constexpr int kRefillMin = IRIS_REFILL_MIN;
+template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire>
+__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
+                                             Retire retire) {
+    RayState r;
+    r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
+    ray_begin(r, r.o, r.d);
+    r.cur = kEmptyRef;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
+    bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
+    bool more = true;              // wave-uniform: the ray list is not exhausted
+    unsigned long long pend = 0;   // wave-uniform: lanes whose next ray has been requested but not activated
+    int max_sp = 0;
+    const int kPhaseMinRt = sc.phase_min;
+    for (;;) {
+        // ---------------- activate the lanes whose ray data was requested in the previous round
+        if (pend) {
+            if ((pend >> (threadIdx.x & 63)) & 1ull) {
+                prepare(r.o, r.d);
+                ray_begin(r, r.o, r.d);
+                st.sp = 0;
+                if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
+            }
+            pend = 0;
+        }
+        // ---------------- retire finished rays + request new ones
+        const bool idle = r.cur == kEmptyRef;
+        const int n_idle = __popcll(__ballot(idle));
+        if (more && (n_idle >= kRefillMin || n_idle == __popcll(__ballot(1)))) {
+            bool got = false;
+            if (idle) {
+                if (live) retire(r.h);
+                live = got = fetch(r.o, r.d);
+            }
+            pend = __ballot(got);
+            if (pend == 0) more = false;
+        }
+        if (__ballot(r.cur != kEmptyRef) == 0) {
+            if (pend == 0 && !more) break;
+            continue;
+        }
+        // ---------------- node phase
+        for (;;) {
+            const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
+            const int n_node = __popcll(__ballot(at_node));
+            if (n_node == 0) break;
+            if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
+            if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
+            if (at_node) {
+                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
+                node_step<LAYOUT>(sc, r, st);
+                if (COUNT) max_sp = max(max_sp, st.sp);
+            }
+            if (pend) break;   // requested rays have had one step to arrive: go activate them
+        }
+        // ---------------- leaf phase
+        for (;;) {
+            const bool at_leaf = r.cur != kEmptyRef && (r.cur & kLeafBit);
+            const int n_leaf = __popcll(__ballot(at_leaf));
+            if (n_leaf == 0) break;
+            if (n_leaf < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && !(r.cur & kLeafBit))) >= kPhaseMinRt) break;
+            if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;
+            if (at_leaf) {
+                if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
+                leaf_step(sc, r, st);
+            }
+            if (pend) break;
+        }
+    }
+    if (live) retire(r.h);
+    if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; }
 }
 
 // Mitsuba Mesh::compute_surface_interaction restated: p = fma(p0,b0,fma(p1,b1,p2*b2)), b0 = (1-b1)-b2;
