@@ -187,8 +187,9 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
 // One tile (<= kTileRays rays = tile_px consecutive valid pixels x spp) of one lobe, by one 256-thread workgroup.
 //   LDS: s_sorted (16 KiB ray list) + s_stack (TILE_STACK KiB traversal stacks; doubles as the sort's key / histogram storage, the
 //   two uses are separated by workgroup barriers) + *s_chunk (cursor into the sorted list).
-//   res: the workgroup's slab of per-ray slots (NC float4 each) in the workspace.  Slot life: phase A parks the sampled direction
-//   (q0 = wi) and the GGX weights (q1 = g1, g0); phase C replaces q0 by the hit (u, v, leaf slot); phase D shades and sums.
+//   res: the workgroup's slab of per-ray slots in the workspace: float4 res[kTileRays], then (specular) float2 res_g[kTileRays].
+//   Slot life: phase A parks the sampled direction (res = wi) and the GGX weights (res_g = g1, g0); phase C replaces res by the
+//   hit (u, v, leaf slot); phase D shades and sums.
 //   The slots are only ever exchanged between waves of THIS workgroup, so __syncthreads() orders them (the waves of a workgroup
 //   share their CU's write-through L1; an agent-scope __threadfence() here flushes that L1 -- including the hot upper BVH levels --
 //   once per tile and was measured 9 % slower per fence pair).
@@ -200,7 +201,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     uint32_t* s_cur = s_hist + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
-    constexpr int NC = SPEC ? 2 : 1;  // float4 per ray
+    float2* res_g = reinterpret_cast<float2*>(res + kTileRays);   // GGX weights (g1, g0): second array of the slab
     int lpp, ppw, rounds;
     reduce_geometry(spp, lpp, ppw, rounds);
     const int sub = lane / lpp, sl = lane - sub * lpp;
@@ -219,9 +220,8 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
         normal_space(n, t, b);
         f3 wi; float g0, g1;
         sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
-        float4* q = res + (size_t)r * NC;
-        q[0] = make_float4(wi.x, wi.y, wi.z, 0.f);
-        if (SPEC) q[1] = make_float4(g1, g0, 0.f, 0.f);
+        res[r] = make_float4(wi.x, wi.y, wi.z, 0.f);
+        if (SPEC) res_g[r] = make_float2(g1, g0);
         const uint32_t key = dir_bin(wi);
         s_keys[r] = (uint8_t)key;
         atomicAdd(&s_hist[key], 1u);
@@ -256,14 +256,14 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
             my_r = s_sorted[i];
             const int64_t p = p0 + my_r / spp;
             o = ld3(a.pos + p * 3);                       // raw: the pixel's position; prepare() offsets it
-            const float4 qa = res[(size_t)my_r * NC];
+            const float4 qa = res[my_r];
             d = mk3(qa.x, qa.y, qa.z);
             if (COUNT) n_rays++;
             return true;
         };
         // position + RayEpsilon*wi (bake_shading.py:117, :180)
         auto prepare = [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); };
-        auto retire = [&](const Hit& h) { res[(size_t)my_r * NC] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f); };
+        auto retire = [&](const Hit& h) { res[my_r] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f); };
         trace_stream<LAYOUT, COUNT, TILE_STACK, true>(a.sc, s_stack + tid, ovf, &ts, fetch, prepare, retire);
     }
     __syncthreads();
@@ -279,8 +279,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
         for (int rr = 0; rr < rounds; ++rr) {
             const int s = rr * 64 + sl;
             if (pvalid && s < spp) {
-                const float4* q = res + (size_t)(pl * spp + s) * NC;
-                const float4 qa = q[0];
+                const float4 qa = res[pl * spp + s];
                 Hit h; h.u = qa.x; h.v = qa.y; h.slot = __float_as_int(qa.z); h.t = 0.f; h.id = 0;
                 f3 pn = mk3(0.f, 0.f, 0.f);
                 int64_t tri = -1;
@@ -294,7 +293,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
                 float epdf; bool vn;
                 const f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
                 if (SPEC) {
-                    const float4 qb = q[1];
+                    const float2 qb = res_g[pl * spp + s];   // (g1, g0)
                     a0x += Le.x * qb.y; a0y += Le.y * qb.y; a0z += Le.z * qb.y;
                     a1x += Le.x * qb.x; a1y += Le.y * qb.x; a1z += Le.z * qb.x;
                 } else { a0x += Le.x; a0y += Le.y; a0z += Le.z; }
