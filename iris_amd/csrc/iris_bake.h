@@ -1,12 +1,13 @@
 // Fused bake kernels (bake_shading.py:108-123 diffuse, :168-188 specular): uniforms -> BRDF sample -> secondary-ray
-// traversal -> SLF / emitter lookup -> weights -> mean over spp, one launch per lobe.
+// traversal -> SLF / emitter lookup -> weights -> mean over spp.
 //
-//   bake_kernel       v1: one pixel per wave, lanes = samples (maximally incoherent rays inside a wave).
-//   bake_tile_kernel  v2: a workgroup owns a TILE of consecutive pixels (<= 8192 rays), bins the tile's rays by direction
-//                     (octahedral 16x16 map, Morton order) with an LDS counting sort, traces them in sorted order (a wave's 64
-//                     rays share a narrow direction cone and nearby origins -> their node fetches coalesce and their
-//                     traversal lengths match), parks per-ray results in a workgroup-private HBM scratch and finally
-//                     reduces each pixel's samples in the SAME fixed order as v1 -> v1 and v2 are bit-identical.
+//   bake_kernel       pixel-per-wave: one pixel per wave, lanes = samples (maximally incoherent rays inside a wave).  The simple
+//                     reference implementation of the fixed reduction order; used for spp > 8192 and as the A/B baseline.
+//   bake_tile_kernel  one lobe per launch: a persistent workgroup owns a TILE of consecutive pixels (~4096 rays), samples and bins
+//                     the tile's rays by direction (octahedral 16x16 map, Morton order) with an LDS counting sort, traces them in
+//                     sorted order with persistent lanes (trace_stream), then shades and reduces each pixel's samples in the SAME
+//                     fixed order as bake_kernel -> bit-identical outputs (tile_body below).
+//   bake_view_kernel  all lobes of a view behind one persistent launch and one tile queue (same tile_body, same bits).
 #pragma once
 #include "iris_trace.h"
 
@@ -19,16 +20,16 @@ struct BakeArgs {
     int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
     float* out0; float* out1; int64_t* tri_next;
     unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
-    // v2 only
+    // tile kernels only
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
-    float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray results between trace and reduce
+    float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
     unsigned int* tile_counter; // zeroed before the launch
-    int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
+    int tile_px;                // pixels per tile (tile_px * spp <= kTileRays; the host aims at ~4096 rays)
 };
 
 constexpr int kTileRays = 8192;
 
-// lanes-per-pixel / pixels-per-wave geometry of the per-pixel reduction (shared by v1 and v2 so that the sums match)
+// lanes-per-pixel / pixels-per-wave geometry of the per-pixel reduction (shared by all bake kernels so that the sums match)
 __device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int& rounds) {
     if (spp >= 64) { lpp = 64; ppw = 1; rounds = (spp + 63) >> 6; }
     else if ((spp & (spp - 1)) == 0) { lpp = spp; ppw = 64 / spp; rounds = 1; }
@@ -110,7 +111,7 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
     }
 }
 
-// ------------------------------------------------------------------------------------------------------- v1
+// ------------------------------------------------------------------------------------------------------- pixel-per-wave kernel
 template <bool SPEC, bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
     flush_stats<COUNT>(a, ts, n_rays);
 }
 
-// ------------------------------------------------------------------------------------------------------- v2
+// ------------------------------------------------------------------------------------------------------- tile kernels
 // Direction bin: octahedral map of the unit vector to [0,1)^2, 16x16 cells, Morton-interleaved (adjacent codes = adjacent cones)
 __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     float inv = 1.0f / (fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);
@@ -352,15 +353,9 @@ struct ViewArgs {
 };
 
 // Same occupancy as the tile kernel: 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B of LDS per workgroup).
-#ifndef IRIS_VIEW_WAVES
-#define IRIS_VIEW_WAVES 6
-#endif
-#ifndef IRIS_VIEW_STACK
-#define IRIS_VIEW_STACK 10
-#endif
 template <int LAYOUT>
-__global__ __launch_bounds__(kBlock, IRIS_VIEW_WAVES) void bake_view_kernel(ViewArgs v) {
-    constexpr int kTileStack = IRIS_VIEW_STACK;
+__global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(ViewArgs v) {
+    constexpr int kTileStack = IRIS_TILE_STACK;
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;

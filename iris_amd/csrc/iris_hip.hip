@@ -624,14 +624,14 @@ static int tile_pixels(int spp) {
     return std::max(1, std::min(kTileRays, std::max(target, spp)) / spp);
 }
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
-static int view_grid_blocks() { return num_cus() * IRIS_VIEW_WAVES; }
+static int view_grid_blocks() { return bake_grid_blocks(); }
 static uint64_t stack_ovf_bytes() {
-    return (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kStackCapacity - std::min(IRIS_TILE_STACK, IRIS_VIEW_STACK)) * kBlock * sizeof(uint32_t);
+    return (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kStackCapacity - IRIS_TILE_STACK) * kBlock * sizeof(uint32_t);
 }
 
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
     if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
-    // [256 B counters][blocks x 8192 x (16|32) B per-ray results]
+    // [256 B counters][blocks x 8192 x (16|32) B per-ray slots]
     // (packing the pixel tensors into 48-B records was measured 7 % SLOWER than reading pos/nrm/wo directly: not done)
     // + [blocks x (96 - LDS depth) x 256 dwords: traversal-stack entries beyond the LDS part]   (specular sizing also serves iris_bake_view)
     const uint64_t blocks = (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks());
