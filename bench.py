@@ -221,14 +221,16 @@ def main():
         # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 --pmc result
         # for the same kernel / workload is reported when the configuration matches (see profiles/traffic_r1.json)
         traffic = None
+        pmc = None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic_r1.json")))
             if args.variant in (0, 2) and abs(tj["rays_per_launch"] - rays_per_launch) < 0.01 * rays_per_launch and info["node_bytes"] == 64:
                 traffic = float(tj["traffic_bytes"])
+                pmc = tj.get("pmc")
         except Exception:
             traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "pmc": pmc,
                               "note": "algorithmic bytes are served by L1/L2/Infinity Cache (working set ~160 MB), so achieved/HBM-peak is not a utilisation figure; "
                                       "the kernel is VALU-issue bound (DESIGN.md section 5); the timed region runs all lobes in one bake_view_kernel launch, launch_ms / achieved are priced on the per-lobe specular "
                                       "kernel (same tile code) in a separate serialised pass and agree with profiles/r1_final_kernel_stats.csv",
