@@ -295,6 +295,48 @@ def test_bake_box_golden(dev, tmp_path):
         assert rel_l2(N(Ls1), g[f"Ls1_{r_idx}"]) <= 1e-4, r_idx
 
 
+def test_bake_open_scene_with_misses(dev, oracle_mod, tmp_path):
+    """The box room WITHOUT its ceiling and one wall: secondary rays escape (tri_next = -1, Le = 0: model/emitter.py:196-203) and some
+    primary rays miss (zeros in the maps, bake_shading.py:126-127).  Every bit against the device-arithmetic oracle, all kernels."""
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.utils.dataset import real_ldr
+    from iris_amd.utils.path_tracing import Scene
+    from tools import synth
+    g = golden("bake_box.npz")
+    keep = np.ones(len(g["faces"]), bool); keep[[2, 3, 10, 11]] = False          # ceiling (z = Z) and the x = X wall
+    faces = np.ascontiguousarray(g["faces"][keep]); is_em = np.ascontiguousarray(g["is_emitter"][keep])
+    ep, sp = _emitter_files(tmp_path, is_em, g["emitter_area"], g["emitter_radiance"][:len(faces)], g["slf_mask"], g["slf_inds"], g["slf_radiance"],
+                            float(g["voxel_min"]), float(g["voxel_max"]))
+    em = SLFEmitter(ep, sp)
+    sc = Scene(g["verts"], faces, device=dev)
+    osc = oracle_mod.Scene(g["verts"], faces)
+    oslf = oracle_mod.VoxelSLF(g["slf_inds"], g["slf_radiance"], float(g["voxel_min"]), float(g["voxel_max"]))
+    oem = oracle_mod.SLFEmitter(is_em, g["emitter_radiance"][:len(faces)], g["emitter_area"], oslf)
+    H, W = 40, 48
+    K, _ = synth.camera(H, W, 0)
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), g["c2w"], False, device=dev)
+    out = bs.bake_view(sc, em, xs, ds, 32, [32] * 6, seed=2, image_width=W)
+    op, on, _, oidx, ovalid = osc.ray_intersect(N(xs), N(ds))
+    assert 0 < ovalid.sum() < H * W and out["n_valid"] == int(ovalid.sum())        # some primary rays leave through the missing wall
+    assert float(out["diffuse"][torch.from_numpy(~ovalid).to(dev)].abs().sum()) == 0.0
+    pos, nrm, wo = op[ovalid], on[ovalid], -N(ds)[ovalid]
+    pix = np.nonzero(ovalid)[0].astype(np.int32)
+    with oracle_mod.device_arithmetic():
+        oLd, otri = oracle_mod.bake(osc, oem, pos, nrm, 32, seed=2, stream=0, pix_id=pix, want_tri=True)
+        oa, ob = oracle_mod.bake(osc, oem, pos, nrm, 32, wo=wo, roughness=np.float32(0.608), seed=2, stream=4, pix_id=pix)
+    assert 0.02 < (otri < 0).mean() < 0.9                                         # escaping secondary rays are exercised
+    valid_t = torch.from_numpy(ovalid).to(dev)
+    np.testing.assert_array_equal(N(out["diffuse"][valid_t]), oLd)
+    np.testing.assert_array_equal(N(out["specular0"][3][valid_t]), oa)
+    np.testing.assert_array_equal(N(out["specular1"][3][valid_t]), ob)
+    for variant in (L.BAKE_PIXEL_PER_WAVE, L.BAKE_TILE_SORTED):                    # per-lobe kernels: same bits, and the same escaped rays
+        Ld, tri = bs.bake_diffuse(sc, em, T(pos, dev), T(nrm, dev), 32, seed=2, stream_id=0, pix_id=T(pix, dev), want_tri=True, variant=variant)
+        np.testing.assert_array_equal(N(tri), otri)
+        np.testing.assert_array_equal(N(Ld), oLd)
+
+
 @pytest.fixture(scope="module")
 def room_setup(dev, oracle_mod, tmp_path_factory):
     """cfg-1-like scene: room(seed=0, ~2e5 triangles), H=256 SLF, 64x64 camera."""
