@@ -537,6 +537,32 @@ def test_view_kernel_many_tiles_per_workgroup(dev, room_setup):
     assert torch.equal(res[2][0], a) and torch.equal(res[2][1], b)         # variant 1 = pixel-per-wave kernel: no result slots at all
 
 
+def test_full_size_1080p_determinism_and_kernel_agreement(dev, room_setup):
+    """BASELINE.json's headline size (1920x1080 x SPP 128; two lobes here): the dynamically scheduled view kernel is bit-reproducible run to
+    run, equals the per-lobe tile kernel, and every row equals the bake of a small pixel subset (shard invariance) -- properties that
+    do not need the oracle at a size it could not finish."""
+    from tools import synth
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.dataset import real_ldr
+    s = room_setup
+    H, W, spp = 1080, 1920, 128
+    K, c2w = synth.camera(H, W, 9)
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
+    g = bs.primary_hits(s["sc"], xs, ds, image_width=W)
+    P = g["position"].shape[0]
+    assert 0.9999 * H * W <= P <= H * W      # (a handful of rays slip through Moeller-Trumbore edge cracks of the displaced walls)
+    args = (s["sc"], s["em"], g["position"], g["normal"], g["wo"], [None, 1.0], [spp, spp])
+    r1 = bs.bake_lobes(*args, seed=13, stream_ids=[0, 6], pix_id=g["pix_id"])
+    r2 = bs.bake_lobes(*args, seed=13, stream_ids=[0, 6], pix_id=g["pix_id"])
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1][0], r2[1][0]) and torch.equal(r1[1][1], r2[1][1])
+    a, b = bs.bake_specular(s["sc"], s["em"], g["position"], g["normal"], g["wo"], 1.0, spp, seed=13, stream_id=6, pix_id=g["pix_id"])
+    assert torch.equal(r1[1][0], a) and torch.equal(r1[1][1], b)
+    sel = torch.arange(11, P, 9973, device=dev)
+    sub = bs.bake_diffuse(s["sc"], s["em"], g["position"][sel], g["normal"][sel], spp, seed=13, stream_id=0, pix_id=g["pix_id"][sel])
+    assert torch.equal(sub, r1[0][sel])
+    assert torch.isfinite(r1[0]).all() and float(r1[0].min()) >= 0.0
+
+
 def test_view_kernel_equals_per_lobe_launches(dev, room_setup):
     """iris_bake_view (all lobes of a view behind one launch / one tile queue) gives the bits of the per-lobe entry points,
     with the reference's per-lobe spp (256 / 64 / 128...) and with a ragged pixel count."""
