@@ -114,6 +114,7 @@ def main():
     n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
 
     ev_pairs = []   # (start,end) HIP events around every specular bake launch, on the launch stream
+    ev_diffuse = [] # the same around the diffuse-lobe launches
 
     def step(record_events=False, gather=True, view=0):
         """One view: rays -> primary hits (this rank's stripes) -> 7 fused lobe kernels -> scatter -> one all_gather."""
@@ -134,7 +135,12 @@ def main():
         ls = bs.LobeStreams(dev, 1 if record_events else args.streams)     # the timing pass serialises the launches
         for l in ([] if pending else lobes):
             if l == 0:
+                if record_events:
+                    d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    d0.record()
                 pending.append((l, ls.run(lambda: bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant))))
+                if record_events:
+                    d1.record(); ev_diffuse.append((d0, d1, P * spp))
             else:
                 if record_events:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -231,6 +237,9 @@ def main():
             traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "pmc": pmc,
+                              "diffuse_lobe_only": ({"launch_ms": round(float(np.mean([a.elapsed_time(b) for a, b, _ in ev_diffuse])), 3),
+                                                     "mrays_per_s": round(float(np.mean([n for _, _, n in ev_diffuse])) / float(np.mean([a.elapsed_time(b) for a, b, _ in ev_diffuse])) / 1e3, 1)}
+                                                    if ev_diffuse else None),
                               "note": "algorithmic bytes are served by L1/L2/Infinity Cache (working set ~160 MB), so achieved/HBM-peak is not a utilisation figure; "
                                       "the kernel is VALU-issue bound (DESIGN.md section 5); the timed region runs all lobes in one bake_view_kernel launch, launch_ms / achieved are priced on the per-lobe specular "
                                       "kernel (same tile code) in a separate serialised pass and agree with profiles/r1_final_kernel_stats.csv",
