@@ -9,7 +9,7 @@
 //                     fixed order as bake_kernel -> bit-identical outputs (tile_body below).
 //   bake_view_kernel  all lobes of a view behind one persistent launch and one tile queue (same tile_body, same bits).
 #pragma once
-#include "iris_trace.h"
+#include "iris_tile.h"
 
 namespace iris {
 
@@ -161,23 +161,6 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------- tile kernels
-// Direction bin: octahedral map of the unit vector to [0,1)^2, 16x16 cells, Morton-interleaved (adjacent codes = adjacent cones)
-__device__ __forceinline__ uint32_t dir_bin(f3 d) {
-    float inv = 1.0f / (fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);
-    float px = d.x * inv, py = d.y * inv;
-    if (d.z < 0.f) {
-        float qx = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
-        float qy = (1.f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
-        px = qx; py = qy;
-    }
-    int ix = min(15, max(0, (int)((px * 0.5f + 0.5f) * 16.f)));
-    int iy = min(15, max(0, (int)((py * 0.5f + 0.5f) * 16.f)));
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m |= (((uint32_t)ix >> k) & 1u) << (2 * k) | (((uint32_t)iy >> k) & 1u) << (2 * k + 1);
-    return m;
-}
-
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU)
 #define IRIS_TILE_WAVES 6
 #endif
@@ -197,9 +180,6 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
 template <bool SPEC, bool COUNT, int LAYOUT, int TILE_STACK>
 __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
                                           uint32_t* ovf, TraceStats& ts, uint32_t& n_rays) {
-    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
-    uint32_t* s_hist = s_stack + kTileRays / 4;     // zeroed by the caller before the barrier that published the tile index
-    uint32_t* s_cur = s_hist + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
     float2* res_g = reinterpret_cast<float2*>(res + kTileRays);   // GGX weights (g1, g0): second array of the slab
@@ -211,63 +191,32 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     const int np = (int)min((int64_t)a.tile_px, a.P - p0);
     const int nr = np * spp;
 
-    // ---- phase A: sample every ray of the tile (uniforms -> direction + GGX weights), park it, histogram of the direction bins
-    for (int r = tid; r < nr; r += kBlock) {
-        const int pl = r / spp, s = r - pl * spp;
-        const int64_t p = p0 + pl;
-        const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
-        const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
-        f3 t, b;
-        normal_space(n, t, b);
-        f3 wi; float g0, g1;
-        sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
-        res[r] = make_float4(wi.x, wi.y, wi.z, 0.f);
-        if (SPEC) res_g[r] = make_float2(g1, g0);
-        const uint32_t key = dir_bin(wi);
-        s_keys[r] = (uint8_t)key;
-        atomicAdd(&s_hist[key], 1u);
-    }
-    __syncthreads();
-    // ---- exclusive prefix over the 256 bins (wave 0: 4 bins per lane)
-    if (wave == 0) {
-        uint32_t c0 = s_hist[lane * 4], c1 = s_hist[lane * 4 + 1], c2 = s_hist[lane * 4 + 2], c3 = s_hist[lane * 4 + 3];
-        uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
-        for (int m = 1; m < 64; m <<= 1) { uint32_t v = __shfl_up(inc, m); if (lane >= m) inc += v; }
-        uint32_t ex = inc - tot;
-        s_cur[lane * 4] = ex; s_cur[lane * 4 + 1] = ex + c0; s_cur[lane * 4 + 2] = ex + c0 + c1; s_cur[lane * 4 + 3] = ex + c0 + c1 + c2;
-    }
-    __syncthreads();
-    // ---- phase B: scatter ray ids into bin order (order inside a bin is irrelevant: results go to per-ray slots)
-    for (int r = tid; r < nr; r += kBlock) {
-        const uint32_t pos = atomicAdd(&s_cur[s_keys[r]], 1u);
-        s_sorted[pos] = (uint16_t)r;
-    }
-    __syncthreads();  // keys / histogram dead from here on: the region becomes the traversal stacks
-
-    // ---- phase C: persistent-lane traversal of the sorted list (trace_stream): idle lanes claim the next rays together
-    {
-        int my_r = 0;
-        auto fetch = [&](f3& o, f3& d) -> bool {
-            const unsigned long long m = __ballot(1);
-            int base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_chunk, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int i = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (i >= nr) return false;
-            my_r = s_sorted[i];
-            const int64_t p = p0 + my_r / spp;
+    // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
+    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
+        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
+        [&](int r) -> uint32_t {
+            const int pl = r / spp, s = r - pl * spp;
+            const int64_t p = p0 + pl;
+            const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
+            const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
+            f3 t, b;
+            normal_space(n, t, b);
+            f3 wi; float g0, g1;
+            sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
+            res[r] = make_float4(wi.x, wi.y, wi.z, 0.f);
+            if (SPEC) res_g[r] = make_float2(g1, g0);
+            return dir_bin(wi);
+        },
+        [&](int r, f3& o, f3& d) {
+            const int64_t p = p0 + r / spp;
             o = ld3(a.pos + p * 3);                       // raw: the pixel's position; prepare() offsets it
-            const float4 qa = res[my_r];
+            const float4 qa = res[r];
             d = mk3(qa.x, qa.y, qa.z);
             if (COUNT) n_rays++;
-            return true;
-        };
+        },
         // position + RayEpsilon*wi (bake_shading.py:117, :180)
-        auto prepare = [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); };
-        auto retire = [&](const Hit& h) { res[my_r] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f); };
-        trace_stream<LAYOUT, COUNT, TILE_STACK, true>(a.sc, s_stack + tid, ovf, &ts, fetch, prepare, retire);
-    }
-    __syncthreads();
+        [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); },
+        [&](int r, const Hit& h) { res[r] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f); });
 
     // ---- phase D: shade every sample (hit -> p_next -> eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0),
     // bake_shading.py:121-122, :184-185 -> Le * g) and take the per-pixel mean in the fixed order of the pixel-per-wave kernel

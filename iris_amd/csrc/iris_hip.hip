@@ -754,6 +754,18 @@ extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emit
 // ======================================================================================================
 // a9 (cfg 5): path_tracing_single building blocks and stages (iris_pt.h)
 // ======================================================================================================
+// Large batches go through the direction-sorted, persistent-lane tile kernel (iris_pt.h); small ones (cfg 5: 262 144 rays) keep the
+// one-ray-per-thread kernels, which expose more parallelism.  IRIS_PT_TILE_MIN overrides the switch-over (tests force the tile path).
+static bool pt_tiling(int64_t N, int& tile_rays, int& grid) {
+    const int64_t blocks = (int64_t)num_cus() * 6;
+    int64_t min_n = 512 * blocks;
+    if (const char* e = getenv("IRIS_PT_TILE_MIN")) min_n = atoll(e);
+    if (N < min_n) return false;
+    int64_t t = (N / (2 * blocks) + kBlock - 1) / kBlock * kBlock;          // >= 2 tiles per resident workgroup ...
+    tile_rays = (int)std::min<int64_t>(kPtTileCap, std::max<int64_t>(kBlock, t));   // ... of 256 .. 4096 rays
+    grid = (int)std::min<int64_t>(blocks, (N + tile_rays - 1) / tile_rays);
+    return true;
+}
 #define LAUNCH1D(kernel, n, st, ...)                                                                          \
     do {                                                                                                      \
         hipLaunchKernelGGL(kernel, dim3(grid_for((n), 256, 8192)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
@@ -815,7 +827,11 @@ extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e,
     a.sc = sc->dev; a.em = e->dev; a.es = e->sample; a.N = N;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
     a.coef1 = coef1; a.e1 = e1; a.g_eps = g_eps; a.pdf_eps = pdf_eps; a.mis_eps = mis_eps;
-    if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    int tile_rays, grid;
+    if (pt_tiling(N, tile_rays, grid)) {
+        if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL((pt_tiled_kernel<kLayoutQ8, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
+        else hipLaunchKernelGGL((pt_tiled_kernel<kLayoutF32, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
+    } else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_nee_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
@@ -834,7 +850,11 @@ extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* po
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.s1 = s1; a.s2 = s2;
     a.wi_out = wi; a.brdf_pdf = pdf; a.brdf_w = weight; a.pos_next = pos_next; a.nrm_next = nrm_next; a.tri_next = tri_next; a.valid_next_hit = valid;
     a.lobe = lobe; a.lobe_rough = lobe_roughness;
-    if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    int tile_rays, grid;
+    if (pt_tiling(N, tile_rays, grid)) {
+        if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL((pt_tiled_kernel<kLayoutQ8, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
+        else hipLaunchKernelGGL((pt_tiled_kernel<kLayoutF32, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
+    } else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;

@@ -8,7 +8,7 @@
 // (SURVEY.md section 3.4), and L is linear in it: every stage emits (emitter ordinal, rgb coefficient) pairs; the forward
 // pass is a gather, the backward pass the matching scatter-add.
 #pragma once
-#include "iris_trace.h"
+#include "iris_tile.h"
 
 namespace iris {
 
@@ -111,8 +111,54 @@ __device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
     return m;
 }
 
+// hit triangle of a leaf slot: vertices + original triangle index
+__device__ __forceinline__ void hit_triangle(const SceneDev& sc, int slot, f3& p0, f3& p1, f3& p2, int& id) {
+    const float4* r = sc.tris + (int64_t)slot * 3;
+    const float4 a = r[0], b = r[1], c = r[2];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(a.w, b.x, b.y); p2 = mk3(b.z, b.w, c.x);
+    id = __float_as_int(c.y);
+}
+
 // utils/path_tracing.py:357-382: emitter sampling, visibility ray, geometry term, eval_brdf, power-2 MIS.
 // term1 = coef1 * radiance[e1]   (e1 = -1 -> no contribution)
+// everything after the visibility ray: (slot, u, v) = its closest hit (slot < 0: miss)
+__device__ __forceinline__ void pt_nee_finish(const PtArgs& a, int64_t i, f3 x, f3 n, f3 wo, f3 wi, float emit_pdf, int64_t emit_tri, int slot, float u,
+                                              float v) {
+    const bool emit_valid = slot >= 0;
+    int ord = -1;
+    float G = 1.f;
+    bool emit_vis = true;                                    // (~emit_valid) | (emit_triangle_idx == triangle_idx)
+    if (emit_valid) {
+        f3 p0, p1, p2; int id;
+        hit_triangle(a.sc, slot, p0, p1, p2, id);
+        Hit h; h.u = u; h.v = v; h.slot = slot; h.t = 0.f; h.id = id;
+        const f3 ep = hit_position(h, p0, p1, p2);
+        f3 en = t_normalize(hit_normal(p0, p1, p2));
+        if (t_dot(en, mk3(-wi.x, -wi.y, -wi.z)) < 0.f) en = mk3(-en.x, -en.y, -en.z);
+        emit_vis = emit_tri == (int64_t)id;
+        ord = a.em.emit_ord[id];                             // eval_emitter(emit_position, wi, triangle_idx): Le = radiance[ord] if emitter
+        const f3 dlt = sub3(ep, x);
+        const float d2 = (dlt.x * dlt.x + dlt.y * dlt.y) + dlt.z * dlt.z;
+        G = fabsf(t_dot(mk3(-wi.x, -wi.y, -wi.z), en)) / fmaxf(d2, a.g_eps);
+    }
+    f3 brdf; float brdf_pdf;
+    eval_brdf1(wi, wo, n, load_mat(a, i), brdf, brdf_pdf);
+    brdf_pdf = brdf_pdf * G;
+    float w_mis = 0.f;
+    if (emit_pdf > 0.f && !isinf(brdf_pdf)) {
+        float den = emit_pdf * emit_pdf + brdf_pdf * brdf_pdf;
+        if (a.mis_eps > 0.f) den = fmaxf(den, a.mis_eps);
+        w_mis = emit_pdf * emit_pdf / den;
+    }
+    if (isinf(emit_pdf) || brdf_pdf == 0.f) w_mis = 1.f;
+    // emit_weight = Le * emit_vis * G / clamp(emit_pdf,eps); L += emit_brdf * emit_weight * w_mis
+    const float s = (emit_vis ? 1.f : 0.f);
+    const float ew = G / fmaxf(emit_pdf, a.pdf_eps);
+    // coefficient applied to radiance[ord]: ((1*vis)*G/pdf) then *brdf then *w_mis, in the reference's evaluation order
+    st3(a.coef1 + i * 3, mk3(brdf.x * (s * ew) * w_mis, brdf.y * (s * ew) * w_mis, brdf.z * (s * ew) * w_mis));
+    a.e1[i] = (emit_valid && ord >= 0) ? ord : -1;
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
@@ -122,78 +168,119 @@ __global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
         sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], x, wi, emit_pdf, emit_tri);
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
         Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
-        const bool emit_valid = h.slot >= 0;
-        int ord = -1;
-        float G = 1.f;
-        bool emit_vis = true;                                    // (~emit_valid) | (emit_triangle_idx == triangle_idx)
-        if (emit_valid) {
-            f3 p0, p1, p2;
-            hit_vertices(a.sc, h, p0, p1, p2);
-            const f3 ep = hit_position(h, p0, p1, p2);
-            f3 en = t_normalize(hit_normal(p0, p1, p2));
-            if (t_dot(en, mk3(-wi.x, -wi.y, -wi.z)) < 0.f) en = mk3(-en.x, -en.y, -en.z);
-            emit_vis = emit_tri == (int64_t)h.id;
-            ord = a.em.emit_ord[h.id];                           // eval_emitter(emit_position, wi, triangle_idx): Le = radiance[ord] if emitter
-            const f3 dlt = sub3(ep, x);
-            const float d2 = (dlt.x * dlt.x + dlt.y * dlt.y) + dlt.z * dlt.z;
-            G = fabsf(t_dot(mk3(-wi.x, -wi.y, -wi.z), en)) / fmaxf(d2, a.g_eps);
-        }
-        f3 brdf; float brdf_pdf;
-        eval_brdf1(wi, wo, n, load_mat(a, i), brdf, brdf_pdf);
-        brdf_pdf = brdf_pdf * G;
-        float w_mis = 0.f;
-        if (emit_pdf > 0.f && !isinf(brdf_pdf)) {
-            float den = emit_pdf * emit_pdf + brdf_pdf * brdf_pdf;
-            if (a.mis_eps > 0.f) den = fmaxf(den, a.mis_eps);
-            w_mis = emit_pdf * emit_pdf / den;
-        }
-        if (isinf(emit_pdf) || brdf_pdf == 0.f) w_mis = 1.f;
-        // emit_weight = Le * emit_vis * G / clamp(emit_pdf,eps); L += emit_brdf * emit_weight * w_mis
-        const float s = (emit_vis ? 1.f : 0.f);
-        const float ew = G / fmaxf(emit_pdf, a.pdf_eps);
-        // coefficient applied to radiance[ord]: ((1*vis)*G/pdf) then *brdf then *w_mis, in the reference's evaluation order
-        st3(a.coef1 + i * 3, mk3(brdf.x * (s * ew) * w_mis, brdf.y * (s * ew) * w_mis, brdf.z * (s * ew) * w_mis));
-        a.e1[i] = (emit_valid && ord >= 0) ? ord : -1;
+        pt_nee_finish(a, i, x, n, wo, wi, emit_pdf, emit_tri, h.slot, h.u, h.v);
     }
 }
 
 // utils/path_tracing.py:384-392: BRDF sampling + next intersection
+// direction, pdf and weight of ray i (lobe 0: sample_brdf; 1: sample_diffuse; 2: sample_specular at lobe_rough)
+__device__ __forceinline__ void pt_sample_dir(const PtArgs& a, int64_t i, f3 wo, f3 n, f3& wi, float& pdf, f3& w) {
+    if (a.lobe == 0) {
+        sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
+    } else {
+        f3 t, b;
+        normal_space(n, t, b);
+        if (a.lobe == 1) {                                   // BaseBRDF.sample_diffuse (model/brdf.py:78-88)
+            wi = diffuse_sampler(a.s2[i * 2], a.s2[i * 2 + 1], n, t, b);
+            pdf = relu(t_dot(n, wi)) / kPi;
+            w = mk3(1.f, 1.f, 1.f);
+        } else {                                             // BaseBRDF.sample_specular (model/brdf.py:112-136)
+            wi = specular_sampler(a.s2[i * 2], a.s2[i * 2 + 1], a.lobe_rough, wo, n, t, b);
+            SpecW sw = specular_weights(wi, wo, n, a.lobe_rough, true);
+            pdf = sw.pdf;
+            w = mk3(sw.g0, sw.g1, 0.f);
+        }
+    }
+}
+// next-hit outputs of ray i from its closest hit (slot, u, v)
+__device__ __forceinline__ void pt_next_hit(const PtArgs& a, int64_t i, f3 wi, int slot, float u, float v) {
+    f3 pn = mk3(0.f, 0.f, 0.f), nn = mk3(0.f, 0.f, 0.f);
+    int64_t tri = -1;
+    if (slot >= 0) {
+        f3 p0, p1, p2; int id;
+        hit_triangle(a.sc, slot, p0, p1, p2, id);
+        Hit h; h.u = u; h.v = v; h.slot = slot; h.t = 0.f; h.id = id;
+        pn = hit_position(h, p0, p1, p2);
+        nn = t_normalize(hit_normal(p0, p1, p2));
+        if (t_dot(nn, mk3(-wi.x, -wi.y, -wi.z)) < 0.f) nn = mk3(-nn.x, -nn.y, -nn.z);
+        tri = id;
+    }
+    st3(a.pos_next + i * 3, pn); st3(a.nrm_next + i * 3, nn); a.tri_next[i] = tri; a.valid_next_hit[i] = slot >= 0;
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
         const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
         f3 wi, w; float pdf;
-        if (a.lobe == 0) {
-            sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
-        } else {
-            f3 t, b;
-            normal_space(n, t, b);
-            if (a.lobe == 1) {                                   // BaseBRDF.sample_diffuse (model/brdf.py:78-88)
-                wi = diffuse_sampler(a.s2[i * 2], a.s2[i * 2 + 1], n, t, b);
-                pdf = relu(t_dot(n, wi)) / kPi;
-                w = mk3(1.f, 1.f, 1.f);
-            } else {                                             // BaseBRDF.sample_specular (model/brdf.py:112-136)
-                wi = specular_sampler(a.s2[i * 2], a.s2[i * 2 + 1], a.lobe_rough, wo, n, t, b);
-                SpecW sw = specular_weights(wi, wo, n, a.lobe_rough, true);
-                pdf = sw.pdf;
-                w = mk3(sw.g0, sw.g1, 0.f);
-            }
-        }
+        pt_sample_dir(a, i, wo, n, wi, pdf, w);
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
         Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
-        f3 pn = mk3(0.f, 0.f, 0.f), nn = mk3(0.f, 0.f, 0.f);
-        int64_t tri = -1;
-        if (h.slot >= 0) {
-            f3 p0, p1, p2;
-            hit_vertices(a.sc, h, p0, p1, p2);
-            pn = hit_position(h, p0, p1, p2);
-            nn = t_normalize(hit_normal(p0, p1, p2));
-            if (t_dot(nn, mk3(-wi.x, -wi.y, -wi.z)) < 0.f) nn = mk3(-nn.x, -nn.y, -nn.z);
-            tri = h.id;
-        }
         st3(a.wi_out + i * 3, wi); a.brdf_pdf[i] = pdf; st3(a.brdf_w + i * 3, w);
-        st3(a.pos_next + i * 3, pn); st3(a.nrm_next + i * 3, nn); a.tri_next[i] = tri; a.valid_next_hit[i] = h.slot >= 0;
+        pt_next_hit(a, i, wi, h.slot, h.u, h.v);
+    }
+}
+
+// ---- large batches (refine_shading's whole-image calls): the same two stages through the tile machinery of iris_tile.h --
+// rays binned by direction per tile, persistent-lane traversal.  Nothing needs a workspace: the sampled direction is parked in an
+// output array of the stage (NEE: coef1, BRDF stage: wi_out), the hit (u, v, leaf slot) in another (NEE: coef1 + e1, BRDF stage:
+// pos_next) until the epilogue overwrites them with the final values.  Same per-ray arithmetic as the kernels above: same bits.
+constexpr int kPtTileCap = 4096, kPtTileStack = 10;
+
+template <int LAYOUT, bool NEE>
+__global__ __launch_bounds__(kBlock, 6) void pt_tiled_kernel(PtArgs a, int tile_rays) {
+    __shared__ uint16_t s_sorted[kPtTileCap];
+    __shared__ uint32_t s_stack[kPtTileStack * kBlock];
+    __shared__ int s_chunk;
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (a.N + tile_rays - 1) / tile_rays;
+    TraceStats ts;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        if (tid == 0) s_chunk = 0;
+        (s_stack + kPtTileCap / 4)[tid] = 0;
+        __syncthreads();
+        const int64_t i0 = tile * tile_rays;
+        const int nr = (int)min((int64_t)tile_rays, a.N - i0);
+        float* dir = NEE ? a.coef1 : a.wi_out;       // where the direction is parked
+        float* rec = NEE ? a.coef1 : a.pos_next;     // where (u, v[, slot]) is parked
+        tile_sort_trace<LAYOUT, false, kPtTileCap, kPtTileStack, false>(
+            a.sc, nr, s_sorted, s_stack, &s_chunk, nullptr, ts,
+            [&](int r) -> uint32_t {
+                const int64_t i = i0 + r;
+                f3 wi;
+                if (NEE) {
+                    float emit_pdf; int64_t emit_tri;
+                    sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], ld3(a.pos + i * 3), wi, emit_pdf, emit_tri);
+                } else {
+                    f3 w; float pdf;
+                    pt_sample_dir(a, i, ld3(a.wo + i * 3), ld3(a.nrm + i * 3), wi, pdf, w);
+                    a.brdf_pdf[i] = pdf; st3(a.brdf_w + i * 3, w);
+                }
+                st3(dir + i * 3, wi);
+                return dir_bin(wi);
+            },
+            [&](int r, f3& o, f3& d) { const int64_t i = i0 + r; o = ld3(a.pos + i * 3); d = ld3(dir + i * 3); },
+            [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); },
+            [&](int r, const Hit& h) {
+                const int64_t i = i0 + r;
+                if (NEE) { rec[i * 3] = h.u; rec[i * 3 + 1] = h.v; a.e1[i] = h.slot; }
+                else st3(rec + i * 3, mk3(h.u, h.v, __int_as_float(h.slot)));
+            });
+        // epilogue: final outputs from the parked hit
+        for (int r = tid; r < nr; r += kBlock) {
+            const int64_t i = i0 + r;
+            if (NEE) {
+                const f3 x = ld3(a.pos + i * 3);
+                f3 wi; float emit_pdf; int64_t emit_tri;
+                sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], x, wi, emit_pdf, emit_tri);   // (the direction slot now holds u, v)
+                pt_nee_finish(a, i, x, ld3(a.nrm + i * 3), ld3(a.wo + i * 3), wi, emit_pdf, emit_tri, a.e1[i], rec[i * 3], rec[i * 3 + 1]);
+            } else {
+                const f3 h = ld3(rec + i * 3);
+                pt_next_hit(a, i, ld3(a.wi_out + i * 3), __float_as_int(h.z), h.x, h.y);
+            }
+        }
     }
 }
 

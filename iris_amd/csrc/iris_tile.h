@@ -1,0 +1,87 @@
+// Tile machinery shared by the bake kernels (iris_bake.h) and the large-batch path-tracing stages (iris_pt.h):
+// a 256-thread workgroup takes a tile of <= CAP rays, bins them by direction with an LDS counting sort and traces them in sorted
+// order with persistent lanes (trace_stream).  What a "ray" is -- how it is sampled, where its direction is parked, what happens
+// with the hit -- is supplied by the caller as functors.
+#pragma once
+#include "iris_trace.h"
+
+namespace iris {
+
+// Direction bin: octahedral map of the unit vector to [0,1)^2, 16x16 cells, Morton-interleaved (adjacent codes = adjacent cones)
+__device__ __forceinline__ uint32_t dir_bin(f3 d) {
+    float inv = 1.0f / (fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);
+    float px = d.x * inv, py = d.y * inv;
+    if (d.z < 0.f) {
+        float qx = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
+        float qy = (1.f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
+        px = qx; py = qy;
+    }
+    int ix = min(15, max(0, (int)((px * 0.5f + 0.5f) * 16.f)));
+    int iy = min(15, max(0, (int)((py * 0.5f + 0.5f) * 16.f)));
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m |= (((uint32_t)ix >> k) & 1u) << (2 * k) | (((uint32_t)iy >> k) & 1u) << (2 * k + 1);
+    return m;
+}
+
+// LDS contract: s_sorted[CAP] (uint16 ray list), s_stack[TILE_STACK * 256] (traversal stacks; doubles as the sort's key / histogram /
+// cursor storage: CAP bytes of keys, then 256 + 256 words -- the uses are separated by workgroup barriers), *s_chunk (cursor).
+// Before the call the caller has zeroed the histogram (s_stack + CAP/4, 256 words) and *s_chunk and passed a barrier.
+//   phase_a(r) -> direction bin : sample ray r of the tile and park whatever phase C / the caller's epilogue need
+//   fetch_ray(r, o, d)          : ISSUE the loads of ray r's raw origin / direction (no dependent arithmetic)
+//   prepare(o, d)               : raw -> actual origin / direction (first use of the loaded values)
+//   retire(r, h)                : store the hit of ray r
+// Everything exchanged through global memory here stays inside ONE workgroup, so __syncthreads() orders it (the waves of a
+// workgroup share their CU's write-through L1; an agent-scope __threadfence() would flush that L1 -- including the hot upper BVH
+// levels -- once per tile and was measured 9 % slower per fence pair).  Ends with a barrier: hits are visible to the caller.
+template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, class PhaseA, class FetchRay, class Prepare, class Retire>
+__device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk, uint32_t* ovf,
+                                                TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare, Retire retire) {
+    static_assert(TILE_STACK * kBlock * 4 >= CAP + 2 * 256 * 4, "stack region too small to alias the sort keys");
+    uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
+    uint32_t* s_hist = s_stack + CAP / 4;
+    uint32_t* s_cur = s_hist + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- phase A: sample, park, histogram of the direction bins
+    for (int r = tid; r < nr; r += kBlock) {
+        const uint32_t key = phase_a(r);
+        s_keys[r] = (uint8_t)key;
+        atomicAdd(&s_hist[key], 1u);
+    }
+    __syncthreads();
+    // ---- exclusive prefix over the 256 bins (wave 0: 4 bins per lane)
+    if (wave == 0) {
+        uint32_t c0 = s_hist[lane * 4], c1 = s_hist[lane * 4 + 1], c2 = s_hist[lane * 4 + 2], c3 = s_hist[lane * 4 + 3];
+        uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
+        for (int m = 1; m < 64; m <<= 1) { uint32_t v = __shfl_up(inc, m); if (lane >= m) inc += v; }
+        uint32_t ex = inc - tot;
+        s_cur[lane * 4] = ex; s_cur[lane * 4 + 1] = ex + c0; s_cur[lane * 4 + 2] = ex + c0 + c1; s_cur[lane * 4 + 3] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+    // ---- phase B: scatter ray ids into bin order (order inside a bin is irrelevant: hits go to per-ray slots)
+    for (int r = tid; r < nr; r += kBlock) {
+        const uint32_t pos = atomicAdd(&s_cur[s_keys[r]], 1u);
+        s_sorted[pos] = (uint16_t)r;
+    }
+    __syncthreads();  // keys / histogram dead from here on: the region becomes the traversal stacks
+    // ---- phase C: persistent-lane traversal of the sorted list: idle lanes claim the next rays together
+    {
+        int my_r = 0;
+        auto fetch = [&](f3& o, f3& d) -> bool {
+            const unsigned long long m = __ballot(1);
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_chunk, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (i >= nr) return false;
+            my_r = s_sorted[i];
+            fetch_ray(my_r, o, d);
+            return true;
+        };
+        auto ret = [&](const Hit& h) { retire(my_r, h); };
+        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc, s_stack + tid, ovf, &ts, fetch, prepare, ret);
+    }
+    __syncthreads();
+}
+
+}  // namespace iris
