@@ -225,7 +225,7 @@ IRIS_API int iris_shade_cached_bwd(const float *rows, const int64_t *idx, const 
 /* Variance-guided edge-avoiding a-trous filter over (H,W,3) maps, guided by the primary hits of the view: normal / position (H*W,3) f32
  * and valid (H*W) u8 (each nullable: no guide of that kind).  in / out: HOST arrays of n_maps device pointers (in[m] == out[m] allowed);
  * maps are filtered four at a time sharing the geometric weights.  iterations in [1,8] (stride 2^i); defaults used by the Python
- * mirror: 5, sigma_l 4, sigma_n 64, sigma_p 0.1.  Not bit-comparable with OptiX (closed): judged on PSNR against a high-spp bake. */
+ * mirror: 5, sigma_l 16, sigma_n 128, sigma_p 0.05 (tools/tune_denoise.py).  Not bit-comparable with OptiX (closed): judged on PSNR against a high-spp bake. */
 IRIS_API uint64_t iris_denoise_workspace_bytes(int H, int W);
 IRIS_API int iris_denoise(const float *normal, const float *position, const uint8_t *valid, int H, int W, int n_maps, const float *const *in,
                  float *const *out, int iterations, float sigma_l, float sigma_n, float sigma_p, void *workspace, uint64_t workspace_bytes,

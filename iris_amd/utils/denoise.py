@@ -15,7 +15,7 @@ from .. import _lib as L
 
 
 class Denoiser:
-    def __init__(self, size_wh, device="cuda", iterations=5, sigma_l=4.0, sigma_n=64.0, sigma_p=0.1):
+    def __init__(self, size_wh, device="cuda", iterations=5, sigma_l=16.0, sigma_n=128.0, sigma_p=0.05):
         self.W, self.H = int(size_wh[0]), int(size_wh[1])            # OptixDenoiser takes (width, height): bake_shading.py:81
         self.device = torch.device(device)
         self.iterations, self.sigma_l, self.sigma_n, self.sigma_p = int(iterations), float(sigma_l), float(sigma_n), float(sigma_p)

@@ -166,7 +166,7 @@ def shade_cached(rows, idx, albedo, metallic, roughness, gL=None):
 
 
 # ---------------------------------------------------------------- 8(f)-4 denoiser substitute (the build's own filter; no reference counterpart)
-def denoise(img, normal=None, position=None, valid=None, iterations=5, sigma_l=4.0, sigma_n=64.0, sigma_p=0.1):
+def denoise(img, normal=None, position=None, valid=None, iterations=5, sigma_l=16.0, sigma_n=128.0, sigma_p=0.05):
     img = _f32(img); H, W, _ = img.shape
     out = np.empty_like(img)
     normal = None if normal is None else _f32(normal).reshape(-1, 3)
