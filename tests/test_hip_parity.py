@@ -515,6 +515,37 @@ def test_bake_edge_cases(dev, room_setup):
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
 
 
+def test_bake_random_configs_all_kernels_agree(dev, room_setup):
+    """Seeded random configurations (pixel count, spp incl. non-powers of two and > 64, roughness, explicit uniforms or Philox, pixel
+    ids): the pixel-per-wave kernel, the per-lobe tile kernel and the view kernel produce the same bits."""
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    rng = np.random.default_rng(2024)
+    n_all = len(s["pos"])
+    for case in range(24):
+        P = int(rng.choice([1, 2, 63, 64, 65, 257, 1000, n_all]))
+        spp = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 65, 96, 128, 200, 256, 1000]))
+        if P * spp > 600_000:
+            P = max(1, 600_000 // spp)
+        start = int(rng.integers(0, n_all - P + 1))
+        pos, nrm, wo = T(s["pos"][start:start + P], dev), T(s["nrm"][start:start + P], dev), T(s["wo"][start:start + P], dev)
+        rough = float(rng.choice([0.02, 0.216, 0.5, 1.0]))
+        seed, stream = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 7))
+        pix = T(rng.permutation(1 << 20)[:P].astype(np.int32), dev) if rng.random() < 0.5 else None
+        u2 = torch.rand(P * spp, 2, device=dev) if rng.random() < 0.3 else None
+        kw = dict(seed=seed, stream_id=stream, pix_id=pix)
+        d1, t1 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, u2=u2, want_tri=True, variant=L.BAKE_PIXEL_PER_WAVE, **kw)
+        d2, t2 = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, u2=u2, want_tri=True, variant=L.BAKE_TILE_SORTED, **kw)
+        assert torch.equal(t1, t2) and torch.equal(d1, d2), (case, P, spp)
+        a1 = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, rough, spp, u2=u2, variant=L.BAKE_PIXEL_PER_WAVE, **kw)
+        a2 = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, rough, spp, u2=u2, variant=L.BAKE_TILE_SORTED, **kw)
+        assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1]), (case, P, spp, rough)
+        if u2 is None:                                             # the view kernel draws its uniforms itself
+            v = bs.bake_lobes(s["sc"], s["em"], pos, nrm, wo, [None, rough], [spp, spp], seed=seed, stream_ids=[stream, stream], pix_id=pix)
+            assert torch.equal(v[0], d1) and torch.equal(v[1][0], a1[0]) and torch.equal(v[1][1], a1[1]), (case, P, spp, rough)
+
+
 def test_view_kernel_many_tiles_per_workgroup(dev, room_setup):
     """640x480 pixels x 3 lobes: every persistent workgroup of iris_bake_view takes several tiles, so result slots are reused between
     tiles and between lobes; bits must equal the per-lobe launches (themselves bit-exact against the oracle at this size)."""
