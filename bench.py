@@ -245,7 +245,8 @@ def main():
                                       "kernel (same tile code) in a separate serialised pass and agree with profiles/r1_final_kernel_stats.csv",
                               "traffic_note": "bytes per launch (r=1.0 lobe), rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, profiles/traffic_r1.json" if traffic else None,
                               "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
-                              "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3), "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
+                              "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3),
+                              "drain": {"frac_of_node_iterations": round(st[10] / max(st[3], 1), 4), "lane_util": round(st[9] / max(st[10] * 64, 1), 3)}, "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
                               "stack_depth_frac_gt_8_12_16": [round(st[5] / st[0], 4), round(st[6] / st[0], 4), round(st[7] / st[0], 5)],
                               "launch_ms": round(avg_ms, 3), "launch_ms_by_roughness_level": [round(float(np.mean(ms[i::len([l for l in lobes if l > 0])])), 2) for i in range(len([l for l in lobes if l > 0]))],
                               "launches": len(ms), "mrays_per_s_kernel": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1)}

@@ -19,7 +19,8 @@ struct BakeArgs {
     const float* u2; const int32_t* pix_id;
     int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
     float* out0; float* out1; int64_t* tri_next;
-    unsigned long long* stats;  // instrumented launches only: {rays, node visits, tri tests, wave node iters, wave leaf iters}
+    unsigned long long* stats;  // instrumented launches only: 16 slots {rays, node visits, tri tests, wave node iters, wave leaf iters, rays with
+                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, ...}
     // tile kernels only
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
@@ -104,6 +105,12 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
             uint32_t x = v[k];
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + k, (unsigned long long)x);
+        }
+        uint32_t w[2] = {ts.drain_nodes, ts.drain_node_iters};
+        for (int k = 0; k < 2; ++k) {
+            uint32_t x = w[k];
+            for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+            if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 9 + k, (unsigned long long)x);
         }
         unsigned long long y = ts.max_steps64;
         for (int m = 1; m < 64; m <<= 1) y += __shfl_xor(y, m);

@@ -91,6 +91,7 @@ struct TraceStats {
     uint32_t leaf_iters = 0;  // wave-level executions of the triangle test
     uint32_t sp_gt8 = 0, sp_gt12 = 0, sp_gt16 = 0;  // rays whose stack ever exceeded 8 / 12 / 16 entries
     unsigned long long max_steps64 = 0;             // sum over wave-chunks of 64 * (longest ray of the chunk, in node+triangle steps)
+    uint32_t drain_nodes = 0, drain_node_iters = 0; // trace_stream: the same two node counters while the ray list is exhausted (no refill)
 };
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
@@ -289,7 +290,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
             if (at_node) {
-                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
+                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
                 node_step<LAYOUT>(sc, r, st);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }
