@@ -121,8 +121,9 @@ enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED =
  * Ld/Ls0/Ls1: (P,3) = mean over spp of Le, Le*g0, Le*g1.  tri_next (P*spp) int64 nullable debug output.
  * stats: nullable device uint64[16]; when given, an INSTRUMENTED (slower) build of the kernel adds {rays, BVH node
  * visits, triangle tests, wave-level node steps, wave-level triangle steps} to it (used to price the roofline).
- * workspace: device scratch of iris_bake_workspace_bytes() bytes for the tile-sorted kernel (per-ray results parked
- * between the trace and the reduction phases); NULL selects the pixel-per-wave kernel.  Both give identical bits. */
+ * workspace: device scratch of iris_bake_workspace_bytes() bytes for the tile-sorted kernel (8 tile-queue counters, the
+ * workgroups' per-ray slots -- sampled direction, then hit -- and their traversal-stack overflow slabs; contents are
+ * scratch, nothing survives the call); NULL selects the pixel-per-wave kernel.  Both give identical bits. */
 IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular);
 IRIS_API int iris_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                       int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,
