@@ -125,7 +125,7 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
                 std::memcpy(&p[24 + s], &ref, 4);
                 p[28 + s] = 0.f;
             }
-        } else {                         // 64 B: origin.xyz, exps | qlo_x qlo_y qlo_z qhi_x | qhi_y qhi_z - - | ref[4]
+        } else {                         // 64 B: origin.xyz, scale.x | scale.yz, qlo_x, qlo_y | qlo_z, qhi_x, qhi_y, qhi_z | ref[4]
             float org[3], hi3[3];
             for (int k = 0; k < 3; ++k) {
                 org[k] = INFINITY; hi3[k] = -INFINITY;
@@ -153,9 +153,10 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
                 }
             }
             p[0] = org[0]; p[1] = org[1]; p[2] = org[2];
-            std::memcpy(&p[3], &ebytes, 4);
-            std::memcpy(&p[4], q[0], 4); std::memcpy(&p[5], q[1], 4); std::memcpy(&p[6], q[2], 4); std::memcpy(&p[7], q[3], 4);
-            std::memcpy(&p[8], q[4], 4); std::memcpy(&p[9], q[5], 4); p[10] = 0.f; p[11] = 0.f;
+            // the plane scales 2^e are stored as floats (not as exponent bytes): decoding them on the device -- two ALU operations per axis
+            // right behind the load, in front of every slab test -- was measured 10 % slower on the whole bake
+            for (int k = 0; k < 3; ++k) p[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127);
+            for (int k = 0; k < 6; ++k) std::memcpy(&p[6 + k], q[k], 4);
             for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }
     }

@@ -105,8 +105,9 @@ __device__ __forceinline__ bool first_active_lane() {
 constexpr int kPhaseMin = 16;
 
 // Node layouts (iris_hip.h): BVH4_F32 = 128-B node with f32 planes (7 dwordx4 per visit); BVH4_Q8 = 64-B node
-// {origin.xyz, biased exponents | qlo_x qlo_y qlo_z qhi_x | qhi_y qhi_z - - | ref[4]} with 8-bit planes relative to the node's own
-// box (4 dwordx4 per visit): plane = origin + q * 2^e, lo rounded down / hi rounded up, so the decoded box contains the f32 box.
+// {origin.xyz, scale.x | scale.y, scale.z, qlo_x, qlo_y | qlo_z, qhi_x, qhi_y, qhi_z | ref[4]} with 8-bit planes relative to the node's
+// own box (4 dwordx4 per visit): plane = origin + q * scale, scale = 2^e per axis, lo rounded down / hi rounded up, so the decoded box
+// contains the f32 box.
 constexpr int kLayoutF32 = 1, kLayoutQ8 = 3;
 __device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xffu); }
 
@@ -139,13 +140,12 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         const uint4* n = reinterpret_cast<const uint4*>(sc.nodes) + (int64_t)r.cur * 4;
         const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
-        // per-axis: t(q) = q * (2^e * idir) + (origin * idir - o * idir)
-        const float ax = __uint_as_float((hd.w & 0xffu) << 23) * ix, ay = __uint_as_float(((hd.w >> 8) & 0xffu) << 23) * iy,
-                    az = __uint_as_float(((hd.w >> 16) & 0xffu) << 23) * iz;
+        // per-axis: t(q) = q * (scale * idir) + (origin * idir - o * idir), scale = 2^e stored as a float
+        const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
         const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
-        const uint32_t nxq = px ? q1.x : q1.w, fxq = px ? q1.w : q1.x;
-        const uint32_t nyq = py ? q1.y : q2.x, fyq = py ? q2.x : q1.y;
-        const uint32_t nzq = pz ? q1.z : q2.y, fzq = pz ? q2.y : q1.z;
+        const uint32_t nxq = px ? q1.z : q2.y, fxq = px ? q2.y : q1.z;
+        const uint32_t nyq = py ? q1.w : q2.z, fyq = py ? q2.z : q1.w;
+        const uint32_t nzq = pz ? q2.x : q2.w, fzq = pz ? q2.w : q2.x;
 #define IRIS_SLABQ(K, C)                                                                                                          \
     {                                                                                                                             \
         float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), ax, bx), fmaf(ubyte(nyq, C), ay, by)), fmaxf(fmaf(ubyte(nzq, C), az, bz), 0.f)); \
