@@ -222,7 +222,8 @@ def main():
         n_node, n_tri = st[1] / st[0], st[2] / st[0]
         # fixed per-ray traffic: SLF index 4 B + radiance row 16 B + emitter ordinal 4 B + hit-triangle refetch 48 B
         # per-pixel traffic amortised over spp: pos+nrm+wo 36 B + pix_id 4 B in, 24 B out
-        bytes_per_ray = n_node * info["node_bytes"] + n_tri * info["tri_bytes"] + (4 + 16 + 4 + info["tri_bytes"]) + (36 + 4 + 24) / spp
+        tri_read = 48   # of the 64-B record a triangle test reads p0 / e1 / e2 / id (3 x 16 B), the hit-point refetch p0 / p1 / p2 (3 x 16 B)
+        bytes_per_ray = n_node * info["node_bytes"] + n_tri * tri_read + (4 + 16 + 4 + tri_read) + (36 + 4 + 24) / spp
         achieved = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
         # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 --pmc result
         # for the same kernel / workload is reported when the configuration matches (see profiles/traffic_r1.json)

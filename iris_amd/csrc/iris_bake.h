@@ -241,9 +241,9 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
                 f3 pn = mk3(0.f, 0.f, 0.f);
                 int64_t tri = -1;
                 if (h.slot >= 0) {
-                    const float4* tr = a.sc.tris + (int64_t)h.slot * 3;
-                    const float4 ta = tr[0], tb = tr[1], tc = tr[2];
-                    pn = hit_position(h, mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x));
+                    const float4* tr = a.sc.tris + (int64_t)h.slot * 4;
+                    const float4 ta = tr[0], tc = tr[2], te = tr[3];
+                    pn = hit_position(h, mk3(ta.x, ta.y, ta.z), mk3(tc.z, tc.w, te.x), mk3(te.y, te.z, te.w));
                     tri = __float_as_int(tc.y);
                 }
                 if (a.tri_next) a.tri_next[(p0 + pl) * spp + s] = tri;

@@ -160,15 +160,19 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
             for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }
     }
-    // ---- encode leaf triangles (48 B) ----
+    // ---- encode leaf triangles (64 B, one per 64-B line): p0, e1 = p1 - p0, e2 = p2 - p0 (f32 subtractions, exactly what the
+    // Moeller-Trumbore contract computes), original index, then p1, p2 for the hit point ----
     const size_t nt = bvh.tri_order.size();
-    std::vector<float> tris(std::max<size_t>(nt, 1) * 12, 0.f);
+    std::vector<float> tris(std::max<size_t>(nt, 1) * 16, 0.f);
     for (size_t i = 0; i < nt; ++i) {
         int32_t f = bvh.tri_order[i];
-        float* p = tris.data() + i * 12;
+        float* p = tris.data() + i * 16;
+        const float* v0 = verts + (int64_t)faces[(int64_t)f * 3 + 0] * 3;
+        const float* v1 = verts + (int64_t)faces[(int64_t)f * 3 + 1] * 3;
+        const float* v2 = verts + (int64_t)faces[(int64_t)f * 3 + 2] * 3;
         for (int k = 0; k < 3; ++k) {
-            const float* v = verts + (int64_t)faces[(int64_t)f * 3 + k] * 3;
-            p[k * 3 + 0] = v[0]; p[k * 3 + 1] = v[1]; p[k * 3 + 2] = v[2];
+            volatile float e1 = v1[k] - v0[k], e2 = v2[k] - v0[k];   // plain f32 (no excess precision, no contraction)
+            p[k] = v0[k]; p[3 + k] = e1; p[6 + k] = e2; p[10 + k] = v1[k]; p[13 + k] = v2[k];
         }
         std::memcpy(&p[9], &f, 4);
     }
@@ -186,7 +190,7 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
     s->dev.phase_min = kPhaseMin;
     if (const char* e = getenv("IRIS_PHASE_MIN")) s->dev.phase_min = atoi(e);  // tuning knob (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
-    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 48; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
+    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
     s->info.sah_cost = bvh.sah_cost;
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;

@@ -113,9 +113,9 @@ __device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
 
 // hit triangle of a leaf slot: vertices + original triangle index
 __device__ __forceinline__ void hit_triangle(const SceneDev& sc, int slot, f3& p0, f3& p1, f3& p2, int& id) {
-    const float4* r = sc.tris + (int64_t)slot * 3;
-    const float4 a = r[0], b = r[1], c = r[2];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(a.w, b.x, b.y); p2 = mk3(b.z, b.w, c.x);
+    const float4* r = sc.tris + (int64_t)slot * 4;
+    const float4 a = r[0], c = r[2], e = r[3];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(c.z, c.w, e.x); p2 = mk3(e.y, e.z, e.w);
     id = __float_as_int(c.y);
 }
 

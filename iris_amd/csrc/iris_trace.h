@@ -14,7 +14,7 @@ constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
 // Scene as laid out in HBM
 struct SceneDev {
     const float4* nodes;  // layout-dependent; BVH4_F32: 8 x float4 = 128 B per node, 128-B aligned
-    const float4* tris;   // 3 x float4 = 48 B per leaf triangle: (p0.xyz,p1.x) (p1.yz,p2.xy) (p2.z, id, -, -)
+    const float4* tris;   // 4 x float4 = 64 B per leaf triangle: (p0.xyz,e1.x) (e1.yz,e2.xy) (e2.z,id,p1.xy) (p1.z,p2.xyz), e_k = p_k - p0
     int n_nodes;
     int n_tris;
     int phase_min;  // wave-level phase scheduling threshold (see trace_bvh4)
@@ -58,11 +58,12 @@ struct Stack {
 
 // Moeller-Trumbore on leaf record `slot`; arithmetic contract of oracle/iris_oracle.c (explicit fmaf only).
 __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 d, Hit& h) {
-    const float4* r = sc.tris + (int64_t)slot * 3;
+    // 64-B record: (p0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, id, p1.xy) (p1.z, p2.xyz); the edges e1 = p1 - p0, e2 = p2 - p0 were computed by the
+    // host in f32 (the same IEEE subtraction the oracle performs), so the test needs only the first 40 bytes and no subtractions
+    const float4* r = sc.tris + (int64_t)slot * 4;
     float4 a = r[0], b = r[1], c = r[2];
-    f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(a.w, b.x, b.y), p2 = mk3(b.z, b.w, c.x);
+    f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     int id = __float_as_int(c.y);
-    f3 e1 = sub3(p1, p0), e2 = sub3(p2, p0);
     f3 pvec = x_cross(d, e2);
     float det = x_dot(e1, pvec);
     float inv_det = 1.0f / det;
@@ -317,9 +318,9 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
 // Mitsuba Mesh::compute_surface_interaction restated: p = fma(p0,b0,fma(p1,b1,p2*b2)), b0 = (1-b1)-b2;
 // n = normalize(cross(p1-p0,p2-p0)).
 __device__ __forceinline__ void hit_vertices(const SceneDev& sc, const Hit& h, f3& p0, f3& p1, f3& p2) {
-    const float4* r = sc.tris + (int64_t)h.slot * 3;
-    float4 a = r[0], b = r[1], c = r[2];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(a.w, b.x, b.y); p2 = mk3(b.z, b.w, c.x);
+    const float4* r = sc.tris + (int64_t)h.slot * 4;
+    float4 a = r[0], c = r[2], e = r[3];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(c.z, c.w, e.x); p2 = mk3(e.y, e.z, e.w);
 }
 __device__ __forceinline__ f3 hit_position(const Hit& h, f3 p0, f3 p1, f3 p2) {
     float b1 = h.u, b2 = h.v, b0 = (1.f - b1) - b2;
