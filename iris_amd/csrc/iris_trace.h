@@ -118,8 +118,7 @@ struct RayState {
     float ix, iy, iz, nx, ny, nz;   // 1/d and -o/d
     bool px, py, pz;                // direction signs
     Hit h;
-    uint32_t cur;                   // node / leaf reference, kEmptyRef = no work
-    int k;                          // triangles of the current leaf already tested
+    uint32_t cur;                   // node / leaf reference (a leaf reference is consumed in place: start + 1, count - 1 per test), kEmptyRef = no work
 };
 __device__ __forceinline__ void ray_begin(RayState& r, f3 o, f3 d) {
     r.o = o; r.d = d;
@@ -127,7 +126,7 @@ __device__ __forceinline__ void ray_begin(RayState& r, f3 o, f3 d) {
     r.ix = safe_rcp_dir(d.x); r.iy = safe_rcp_dir(d.y); r.iz = safe_rcp_dir(d.z);
     r.nx = -(o.x * r.ix); r.ny = -(o.y * r.iy); r.nz = -(o.z * r.iz);
     r.px = r.ix >= 0.f; r.py = r.iy >= 0.f; r.pz = r.iz >= 0.f;
-    r.cur = 0; r.k = 0;
+    r.cur = 0;
 }
 
 // One internal-node visit of the lanes that are at a node: 4 slab tests, 5-comparator sorting network, near child first.
@@ -186,9 +185,9 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
 // One triangle of the current leaf.
 template <class STACK>
 __device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, STACK& st) {
-    const int start = (int)((r.cur & 0x7fffffffu) >> 3), cnt = (int)(r.cur & 7u);
-    tri_test(sc, start + r.k, r.o, r.d, r.h);
-    if (++r.k >= cnt) { r.k = 0; r.cur = st.sp > 0 ? st.pop() : kEmptyRef; }
+    tri_test(sc, (int)((r.cur & 0x7fffffffu) >> 3), r.o, r.d, r.h);
+    r.cur += 7u;                                                  // leaf ref = leafbit | start << 3 | count: start + 1, count - 1
+    if ((r.cur & 7u) == 0u) r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
 }
 
 // One ray per lane, run to completion (primary rays, the path-tracing stages, the pixel-per-wave bake kernel).
