@@ -92,7 +92,7 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
                                  iris_scene** out) {
     API_BEGIN
     if (!out || nv < 0 || nf < 0 || (nf > 0 && (!verts || !faces))) return fail(IRIS_ERR_ARG, "iris_scene_create: bad arguments");
-    if (nf >= (1 << 28)) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^28 triangles");
+    if (nf >= (1 << 26)) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^26 triangles (32-bit byte offsets into the 64-B records)");
     for (int64_t i = 0; i < nf * 3; ++i)
         if (faces[i] < 0 || faces[i] >= nv) return fail(IRIS_ERR_ARG, "iris_scene_create: face index out of range");
     if (layout == IRIS_BVH_DEFAULT) layout = IRIS_BVH4_Q8;

@@ -60,7 +60,7 @@ struct Stack {
 __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 d, Hit& h) {
     // 64-B record: (p0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, id, p1.xy) (p1.z, p2.xyz); the edges e1 = p1 - p0, e2 = p2 - p0 were computed by the
     // host in f32 (the same IEEE subtraction the oracle performs), so the test needs only the first 40 bytes and no subtractions
-    const float4* r = sc.tris + (int64_t)slot * 4;
+    const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (size_t)((uint32_t)slot << 6));   // 32-bit offset
     float4 a = r[0], b = r[1], c = r[2];
     f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     int id = __float_as_int(c.y);
@@ -137,7 +137,8 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
     const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
     const bool px = r.px, py = r.py, pz = r.pz;
     if (LAYOUT == kLayoutQ8) {
-        const uint4* n = reinterpret_cast<const uint4*>(sc.nodes) + (int64_t)r.cur * 4;
+        // 32-bit byte offset from the (scalar) table base: one shift instead of a 64-bit shift + add per visit (the node table is < 4 GB)
+        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
         const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
         // per-axis: t(q) = q * (scale * idir) + (origin * idir - o * idir), scale = 2^e stored as a float
