@@ -621,11 +621,12 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // ======================================================================================================
 // a3..a7 fused bake kernels (iris_bake.h)
 // ======================================================================================================
-// Pixels per tile: the LDS ray list holds kTileRays = 8192 rays, but 4096-ray tiles measured 5 % faster at 1080p x SPP 128 (8192: 324 ms,
-// 6144: 322, 5120: 319, 4096: 308, 3072: 314, 2048: 326 ms per view): the workgroups' result-slot slabs then total 200 MB instead of 400 MB
-// and stay in the 256 MB Infinity Cache, and the end-of-launch tail is shorter.  IRIS_TILE_TARGET_RAYS overrides (tuning knob).
+// Pixels per tile: the LDS ray list holds kTileRays = 8192 rays, but ~5000-ray tiles are faster at 1080p x SPP 128 (with 32-B slots: 8192: 324 ms
+// per view, 6144: 322, 5120: 319, 4096: 308, 3072: 314, 2048: 326; with today's 24-B slots 4096: 6.99, 5120: 7.04, 6144: 6.98 Grays/s): the
+// workgroups' slot slabs then stay in the 256 MB Infinity Cache, against which stands one low-utilisation drain per wave and tile.
+// IRIS_TILE_TARGET_RAYS overrides (tuning knob).
 static int tile_pixels(int spp) {
-    static const int target = [] { const char* e = getenv("IRIS_TILE_TARGET_RAYS"); return e ? std::min(kTileRays, std::max(64, atoi(e))) : 4096; }();
+    static const int target = [] { const char* e = getenv("IRIS_TILE_TARGET_RAYS"); return e ? std::min(kTileRays, std::max(64, atoi(e))) : 5120; }();
     return std::max(1, std::min(kTileRays, std::max(target, spp)) / spp);
 }
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
