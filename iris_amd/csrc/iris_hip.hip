@@ -155,7 +155,8 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
             p[0] = org[0]; p[1] = org[1]; p[2] = org[2];
             // the plane scales 2^e are stored as floats (not as exponent bytes): decoding them on the device -- two ALU operations per axis
             // right behind the load, in front of every slab test -- was measured 10 % slower on the whole bake
-            for (int k = 0; k < 3; ++k) p[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127);
+            // (times 2^24: the kernel feeds the plane bytes to v_fma_mix_f32 as f16 subnormals q * 2^-24, iris_trace.h node_step)
+            for (int k = 0; k < 3; ++k) p[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127 + 24);
             for (int k = 0; k < 6; ++k) std::memcpy(&p[6 + k], q[k], 4);
             for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }

@@ -29,7 +29,7 @@ struct Hit {
 
 __device__ __forceinline__ float safe_rcp_dir(float d) {
     // keeps (box - o) * idir finite for axis-parallel rays
-    return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : 1.0f / d;
+    return fabsf(d) < 1e-20f ? copysignf(1e20f, d) : 1.0f / d;    // (the quantised nodes store scale * 2^24: scale * idir must stay finite too)
 }
 
 // Per-lane stack: the first LDS_DEPTH entries in LDS; deeper entries (a few % of the rays at depth 10-12) either in a private
@@ -107,8 +107,8 @@ constexpr int kPhaseMin = 16;
 
 // Node layouts (iris_hip.h): BVH4_F32 = 128-B node with f32 planes (7 dwordx4 per visit); BVH4_Q8 = 64-B node
 // {origin.xyz, scale.x | scale.y, scale.z, qlo_x, qlo_y | qlo_z, qhi_x, qhi_y, qhi_z | ref[4]} with 8-bit planes relative to the node's
-// own box (4 dwordx4 per visit): plane = origin + q * scale, scale = 2^e per axis, lo rounded down / hi rounded up, so the decoded box
-// contains the f32 box.
+// own box (4 dwordx4 per visit): plane = origin + q * 2^e per axis (the node stores 2^(e+24) as a float, see node_step), lo rounded down /
+// hi rounded up, so the decoded box contains the f32 box.
 constexpr int kLayoutF32 = 1, kLayoutQ8 = 3;
 __device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xffu); }
 
@@ -141,22 +141,29 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
         const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
-        // per-axis: t(q) = q * (scale * idir) + (origin * idir - o * idir), scale = 2^e stored as a float
+        // per-axis: t(q) = q * 2^e * idir + (origin * idir - o * idir); the node stores 2^(e+24) as a float (see below)
         const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
         const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
         const uint32_t nxq = px ? q1.z : q2.y, fxq = px ? q2.y : q1.z;
         const uint32_t nyq = py ? q1.w : q2.z, fyq = py ? q2.z : q1.w;
         const uint32_t nzq = pz ? q2.x : q2.w, fzq = pz ? q2.w : q2.x;
+        // A plane byte q, zero-extended to 16 bits, IS the f16 subnormal q * 2^-24; v_perm_b32 puts the near and the far byte of one
+        // child into the two halves of a register and v_fma_mix_f32 reads an f16 operand directly: 1 + 2 instructions per axis and child
+        // instead of 2 conversions + 2 FMAs.  The node stores scale * 2^24, so q*2^-24 * (scale*2^24*idir) + b is the same real number,
+        // rounded once by the FMA: the same t as before, bit for bit.
+        typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
+#define IRIS_PLANES(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
 #define IRIS_SLABQ(K, C)                                                                                                          \
     {                                                                                                                             \
-        float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), ax, bx), fmaf(ubyte(nyq, C), ay, by)), fmaxf(fmaf(ubyte(nzq, C), az, bz), 0.f)); \
-        float tf = fminf(fminf(fmaf(ubyte(fxq, C), ax, bx), fmaf(ubyte(fyq, C), ay, by)), fminf(fmaf(ubyte(fzq, C), az, bz), r.h.t)); \
+        const iris_h2 hx = IRIS_PLANES(nxq, fxq, C), hy = IRIS_PLANES(nyq, fyq, C), hz = IRIS_PLANES(nzq, fzq, C);                 \
+        float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
+        float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
         K = tn <= tf ? tn : INFINITY;                                                                                             \
     }
         IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
 #undef IRIS_SLABQ
-        // NB: hipcc sinks the child-reference load (n[3]) behind the hit test; forcing it up front with the other
-        // loads was measured 8 % SLOWER (nodes without a hit skip it)
+#undef IRIS_PLANES
+        // (the four 16-B loads are issued together; sinking the child-reference load behind the hit test is neutral today)
     } else {
         const float4* n = sc.nodes + (int64_t)r.cur * 8;
         const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
