@@ -124,7 +124,8 @@ enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED =
  * workspace: device scratch of iris_bake_workspace_bytes() bytes for the tile-sorted kernel (8 tile-queue counters, the
  * workgroups' per-ray slots -- sampled direction, then hit -- and their traversal-stack overflow slabs; contents are
  * scratch, nothing survives the call); NULL selects the pixel-per-wave kernel.  Both give identical bits. */
-IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular);
+IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular);   /* 0 if spp > iris_bake_tile_max_spp() */
+IRIS_API int iris_bake_tile_max_spp(void);   /* largest spp the tile-sorted / view kernels take (5120: the LDS ray list) */
 IRIS_API int iris_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                       int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,
                       float *Ld, int64_t *tri_next, uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes,
@@ -135,7 +136,7 @@ IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const 
                        uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes, iris_stream_t);
 
 /* All lobes of one view (bake_shading.py:93-204) in ONE launch with one tile queue: n_lobes <= 8; roughness[l] < 0 selects the
- * diffuse lobe (out1[l] may be NULL), otherwise the specular lobe of that roughness; spp[l] <= 8192; Philox uniforms only.
+ * diffuse lobe (out1[l] may be NULL), otherwise the specular lobe of that roughness; spp[l] <= iris_bake_tile_max_spp(); Philox uniforms only.
  * roughness / spp / stream_ids / out0 / out1 are HOST arrays.  Outputs are bit-identical to the per-lobe entry points. */
 IRIS_API int iris_bake_view(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm, const float *wo,
                    const int32_t *pix_id, int64_t P, int n_lobes, const float *roughness, const int32_t *spp,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "iris_shade_cached_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P],
     "iris_denoise_workspace_bytes": [_I32, _I32],
     "iris_denoise": [_P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _F, _F, _F, _P, _U64, _P],
+    "iris_bake_tile_max_spp": [],
     "iris_last_error": [],
     "iris_version": [],
 }

@@ -176,7 +176,7 @@ def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=Non
     levels = roughness_levels().tolist()
     want = [l for l in range(N_ROUGHNESS + 1) if lobes is None or l in lobes]
     spp_of = lambda l: spp_diffuse if l == 0 else spps[l - 1]
-    if P > 0 and want and all(spp_of(l) <= 8192 for l in want):
+    if P > 0 and want and all(spp_of(l) <= int(L.lib().iris_bake_tile_max_spp()) for l in want):
         # one persistent launch for the whole view
         res = bake_lobes(scene, emitter, g["position"], g["normal"], g["wo"], [None if l == 0 else levels[l - 1] for l in want], [spp_of(l) for l in want],
                          seed=seed, stream_ids=want, pix_id=g["pix_id"])

@@ -2,8 +2,8 @@
 // traversal -> SLF / emitter lookup -> weights -> mean over spp.
 //
 //   bake_kernel       pixel-per-wave: one pixel per wave, lanes = samples (maximally incoherent rays inside a wave).  The simple
-//                     reference implementation of the fixed reduction order; used for spp > 8192 and as the A/B baseline.
-//   bake_tile_kernel  one lobe per launch: a persistent workgroup owns a TILE of consecutive pixels (~4096 rays), samples and bins
+//                     reference implementation of the fixed reduction order; used for spp > 5120 and as the A/B baseline.
+//   bake_tile_kernel  one lobe per launch: a persistent workgroup owns a TILE of consecutive pixels (~5120 rays), samples and bins
 //                     the tile's rays by direction (octahedral 16x16 map, Morton order) with an LDS counting sort, traces them in
 //                     sorted order with persistent lanes (trace_stream), then shades and reduces each pixel's samples in the SAME
 //                     fixed order as bake_kernel -> bit-identical outputs (tile_body below).
@@ -25,10 +25,10 @@ struct BakeArgs {
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
     unsigned int* tile_counter; // 8 counters (one per XCD, claim_tile), zeroed before the launch
-    int tile_px;                // pixels per tile (tile_px * spp <= kTileRays; the host aims at ~4096 rays)
+    int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
 };
 
-constexpr int kTileRays = 8192;
+constexpr int kTileRays = 5120;   // capacity of the LDS ray list (10 KiB) = largest spp of the tile kernels; the host aims at tiles of this size
 
 // lanes-per-pixel / pixels-per-wave geometry of the per-pixel reduction (shared by all bake kernels so that the sums match)
 __device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int& rounds) {
@@ -168,15 +168,15 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------- tile kernels
-#ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU)
-#define IRIS_TILE_WAVES 6
+#ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU): 7 x 20 488 B of LDS, 72 VGPRs.
+#define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s
 #endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
 #define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
 #endif
 
 // One tile (<= kTileRays rays = tile_px consecutive valid pixels x spp) of one lobe, by one 256-thread workgroup.
-//   LDS: s_sorted (16 KiB ray list) + s_stack (TILE_STACK KiB traversal stacks; doubles as the sort's key / histogram storage, the
+//   LDS: s_sorted (10 KiB ray list) + s_stack (TILE_STACK KiB traversal stacks; doubles as the sort's key / histogram storage, the
 //   two uses are separated by workgroup barriers) + *s_chunk (cursor into the sorted list).
 //   res: the workgroup's slab of per-ray slots in the workspace: float4 res[kTileRays], then (specular) float2 res_g[kTileRays].
 //   Slot life: phase A parks the sampled direction (res = wi) and the GGX weights (res_g = g1, g0); phase C replaces res by the
@@ -291,7 +291,7 @@ __device__ __forceinline__ long long claim_tile(unsigned int* counters, long lon
 
 template <bool SPEC, bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
-    constexpr int kTileStack = IRIS_TILE_STACK;  // 16384 B ray list + kTileStack KiB stacks + 8 B must fit 160 KiB / IRIS_TILE_WAVES
+    constexpr int kTileStack = IRIS_TILE_STACK;  // 10240 B ray list + kTileStack KiB stacks + 12 B must fit 160 KiB / IRIS_TILE_WAVES
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
@@ -329,7 +329,7 @@ struct ViewArgs {
     ViewLobe lobe[kMaxLobes];
 };
 
-// Same occupancy as the tile kernel: 6 waves per SIMD with 10-entry LDS stacks (16384 + 10240 + 8 B of LDS per workgroup).
+// Same occupancy as the tile kernel: 7 waves per SIMD with 10-entry LDS stacks (10240 + 10240 + 8 B of LDS per workgroup).
 template <int LAYOUT>
 __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(ViewArgs v) {
     constexpr int kTileStack = IRIS_TILE_STACK;

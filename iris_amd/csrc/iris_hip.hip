@@ -622,12 +622,12 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // ======================================================================================================
 // a3..a7 fused bake kernels (iris_bake.h)
 // ======================================================================================================
-// Pixels per tile: the LDS ray list holds kTileRays = 8192 rays, but ~5000-ray tiles are faster at 1080p x SPP 128 (with 32-B slots: 8192: 324 ms
-// per view, 6144: 322, 5120: 319, 4096: 308, 3072: 314, 2048: 326; with today's 24-B slots 4096: 6.99, 5120: 7.04, 6144: 6.98 Grays/s): the
-// workgroups' slot slabs then stay in the 256 MB Infinity Cache, against which stands one low-utilisation drain per wave and tile.
-// IRIS_TILE_TARGET_RAYS overrides (tuning knob).
+// Pixels per tile.  ~5000-ray tiles are the optimum at 1080p x SPP 128 (with 32-B slots: 8192 rays: 324 ms per view, 6144: 322, 5120: 319,
+// 4096: 308, 3072: 314, 2048: 326; with today's 24-B slots 4096: 6.99, 5120: 7.04, 6144: 6.98 Grays/s): larger tiles push the workgroups' slot
+// slabs out of the 256 MB Infinity Cache, smaller ones pay more low-utilisation drains (one per wave and tile).  The LDS ray list is sized for
+// exactly that (kTileRays = 5120), which is what lets 7 workgroups share a CU.  IRIS_TILE_TARGET_RAYS overrides downwards (tuning knob).
 static int tile_pixels(int spp) {
-    static const int target = [] { const char* e = getenv("IRIS_TILE_TARGET_RAYS"); return e ? std::min(kTileRays, std::max(64, atoi(e))) : 5120; }();
+    static const int target = [] { const char* e = getenv("IRIS_TILE_TARGET_RAYS"); return e ? std::min(kTileRays, std::max(64, atoi(e))) : kTileRays; }();
     return std::max(1, std::min(kTileRays, std::max(target, spp)) / spp);
 }
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
@@ -636,9 +636,10 @@ static uint64_t stack_ovf_bytes() {
     return (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kStackCapacity - IRIS_TILE_STACK) * kBlock * sizeof(uint32_t);
 }
 
+extern "C" IRIS_API int iris_bake_tile_max_spp(void) { return kTileRays; }
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
     if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
-    // [256 B counters][blocks x 8192 x (16|32) B per-ray slots]
+    // [256 B counters][blocks x kTileRays x (16|32) B per-ray slots]
     // (packing the pixel tensors into 48-B records was measured 7 % SLOWER than reading pos/nrm/wo directly: not done)
     // + [blocks x (96 - LDS depth) x 256 dwords: traversal-stack entries beyond the LDS part]   (specular sizing also serves iris_bake_view)
     const uint64_t blocks = (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks());
@@ -661,7 +662,7 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     const uint64_t need = iris_bake_workspace_bytes(P, spp, spec ? 1 : 0);
     bool tiled = variant != IRIS_BAKE_PIXEL_PER_WAVE && need > 0 && workspace && workspace_bytes >= need;
     if (variant == IRIS_BAKE_TILE_SORTED && !tiled)
-        return fail(IRIS_ERR_ARG, "iris_bake: the tile-sorted kernel needs spp <= 8192 and a workspace of iris_bake_workspace_bytes()");
+        return fail(IRIS_ERR_ARG, "iris_bake: the tile-sorted kernel needs spp <= iris_bake_tile_max_spp() and a workspace of iris_bake_workspace_bytes()");
     hipStream_t st = (hipStream_t)stream;
     if (tiled) {
         const int blocks = bake_grid_blocks();
@@ -724,7 +725,7 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     const int blocks = view_grid_blocks();
     long long t = 0;
     for (int l = 0; l < n_lobes; ++l) {
-        if (spp[l] < 1 || spp[l] > kTileRays) return fail(IRIS_ERR_ARG, "iris_bake_view: spp must be in [1, 8192]");
+        if (spp[l] < 1 || spp[l] > kTileRays) return fail(IRIS_ERR_ARG, "iris_bake_view: spp must be in [1, iris_bake_tile_max_spp()]");
         if (!out0[l] || (roughness[l] >= 0.f && !out1[l])) return fail(IRIS_ERR_ARG, "iris_bake_view: null output");
         int tile_px = tile_pixels(spp[l]);
         const int64_t even = (P * n_lobes + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4);   // >= ~4 tiles per workgroup over the whole view

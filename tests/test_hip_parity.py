@@ -492,7 +492,7 @@ def test_bake_view_layout(dev, room_setup):
 
 
 def test_bake_edge_cases(dev, room_setup):
-    """empty pixel list, a single pixel, spp above the tile kernel's 8192-ray limit (falls back to the pixel-per-wave kernel),
+    """empty pixel list, a single pixel, spp above the tile kernel's limit (falls back to the pixel-per-wave kernel),
     default pix_id, and the workspace contract."""
     from iris_amd import _lib as L
     from iris_amd import bake_shading as bs
@@ -511,7 +511,11 @@ def test_bake_edge_cases(dev, room_setup):
         bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 9000, seed=4, variant=L.BAKE_TILE_SORTED)
     with pytest.raises(L.IrisError):
         bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 16, u2=torch.rand(5, 2, device=dev))     # wrong number of uniforms
-    a, b = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, torch.tensor(1.0), 8192, seed=1)  # largest tile-kernel spp, 0-d tensor roughness
+    top = int(L.lib().iris_bake_tile_max_spp())
+    assert top == 5120 and int(L.lib().iris_bake_workspace_bytes(3, top, 0)) > 0 and int(L.lib().iris_bake_workspace_bytes(3, top + 1, 0)) == 0
+    a, b = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, torch.tensor(1.0), top, seed=1)    # largest tile-kernel spp, 0-d tensor roughness
+    a1, b1 = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 1.0, top, seed=1, variant=L.BAKE_PIXEL_PER_WAVE)
+    assert torch.equal(a, a1) and torch.equal(b, b1)
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
 
 
