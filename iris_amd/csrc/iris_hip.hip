@@ -765,7 +765,7 @@ extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emit
 // Large batches go through the direction-sorted, persistent-lane tile kernel (iris_pt.h); small ones (cfg 5: 262 144 rays) keep the
 // one-ray-per-thread kernels, which expose more parallelism.  IRIS_PT_TILE_MIN overrides the switch-over (tests force the tile path).
 static bool pt_tiling(int64_t N, int& tile_rays, int& grid) {
-    const int64_t blocks = (int64_t)num_cus() * 6;
+    const int64_t blocks = (int64_t)num_cus() * IRIS_PT_WAVES;
     int64_t min_n = 512 * blocks;
     if (const char* e = getenv("IRIS_PT_TILE_MIN")) min_n = atoll(e);
     if (N < min_n) return false;

@@ -227,9 +227,12 @@ __global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
 // output array of the stage (NEE: coef1, BRDF stage: wi_out), the hit (u, v, leaf slot) in another (NEE: coef1 + e1, BRDF stage:
 // pos_next) until the epilogue overwrites them with the final values.  Same per-ray arithmetic as the kernels above: same bits.
 constexpr int kPtTileCap = 4096, kPtTileStack = 10;
+#ifndef IRIS_PT_WAVES
+#define IRIS_PT_WAVES 6
+#endif
 
 template <int LAYOUT, bool NEE>
-__global__ __launch_bounds__(kBlock, 6) void pt_tiled_kernel(PtArgs a, int tile_rays) {
+__global__ __launch_bounds__(kBlock, IRIS_PT_WAVES) void pt_tiled_kernel(PtArgs a, int tile_rays) {
     __shared__ uint16_t s_sorted[kPtTileCap];
     __shared__ uint32_t s_stack[kPtTileStack * kBlock];
     __shared__ int s_chunk;
