@@ -238,6 +238,12 @@ def main():
             traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "pmc": pmc,
+                              # the bound that actually binds: VALU issue.  wave-instructions per ray from the committed PMC run x the live kernel rate,
+                              # against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+                              "valu_issue": ({"achieved_Gwinst_per_s": round(pmc["wave_instructions_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / 1e9, 1),
+                                              "peak_Gwinst_per_s": round(1024 * 2.4e9 / 4 / 1e9, 1),
+                                              "frac": round(pmc["wave_instructions_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / (1024 * 2.4e9 / 4), 3),
+                                              "simd_lane_utilisation": pmc.get("simd_lane_utilisation")} if pmc else None),
                               "diffuse_lobe_only": ({"launch_ms": round(float(np.mean([a.elapsed_time(b) for a, b, _ in ev_diffuse])), 3),
                                                      "mrays_per_s": round(float(np.mean([n for _, _, n in ev_diffuse])) / float(np.mean([a.elapsed_time(b) for a, b, _ in ev_diffuse])) / 1e3, 1)}
                                                     if ev_diffuse else None),
