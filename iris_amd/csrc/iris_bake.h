@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
     const int tid = threadIdx.x;
     constexpr int NC = SPEC ? 2 : 1;
     float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
-    uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock + tid;
+    uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform (Stack adds the lane)
     const int64_t n_tiles = (a.P + a.tile_px - 1) / a.tile_px;
     TraceStats ts;
     uint32_t n_rays = 0;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
     float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
-    uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock + tid;   // no private scratch in this kernel
+    uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform; no private scratch in this kernel
     for (;;) {
         __syncthreads();
         if (tid == 0) { s_tile = (int)claim_tile(v.base.tile_counter, v.n_tiles); s_chunk = 0; }

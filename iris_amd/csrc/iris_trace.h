@@ -39,19 +39,19 @@ constexpr int kStackCapacity = kStackLds + kStackSpill;
 template <int LDS_DEPTH, bool GLOBAL_OVF = false>
 struct Stack {
     uint32_t* lds;  // &s_stack[threadIdx.x]
-    uint32_t* ovf;  // GLOBAL_OVF: &slab[threadIdx.x]
+    uint32_t* ovf;  // GLOBAL_OVF: the workgroup's slab (wave-uniform: stays in scalar registers; the lane offset is added at the rare use)
     uint32_t spill[GLOBAL_OVF ? 1 : kStackCapacity - LDS_DEPTH];
     int sp;
     __device__ __forceinline__ void push(uint32_t v) {
         if (sp < LDS_DEPTH) lds[sp * kBlock] = v;
-        else if (GLOBAL_OVF) ovf[(size_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock] = v;
+        else if (GLOBAL_OVF) ovf[(uint32_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock + threadIdx.x] = v;
         else spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)] = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
         if (sp < LDS_DEPTH) return lds[sp * kBlock];
-        if (GLOBAL_OVF) return ovf[(size_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock];
+        if (GLOBAL_OVF) return ovf[(uint32_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock + threadIdx.x];
         return spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)];
     }
 };
