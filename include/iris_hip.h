@@ -42,8 +42,8 @@ enum { IRIS_OK = 0, IRIS_ERR_ARG = 1, IRIS_ERR_HIP = 2, IRIS_ERR_BUILD = 3 };
 
 #define IRIS_RAY_EPSILON 8.940696716308594e-05f /* mitsuba.math.RayEpsilon (float32) = 1500 * 2^-24 */
 
-/* BVH layouts selectable at scene creation (kernel-choice experiments) */
-enum { IRIS_BVH_DEFAULT = 0, IRIS_BVH4_F32 = 1 /* 128-B nodes, f32 planes */, IRIS_BVH4_Q8 = 3 /* 64-B nodes, 8-bit planes (default) */ };
+/* BVH node layouts (reported by iris_scene_get_info; iris_scene_create always builds IRIS_BVH4_Q8) */
+enum { IRIS_BVH_DEFAULT = 0, IRIS_BVH4_F32 = 1 /* 128-B nodes, f32 planes (A/B baseline, iris_hip_debug.h) */, IRIS_BVH4_Q8 = 3 /* 64-B nodes, 8-bit planes */ };
 
 typedef struct {
     int64_t n_vertices, n_triangles;
@@ -60,8 +60,7 @@ typedef struct {
 /* ---- handles ----------------------------------------------------------------------------------------- */
 
 /* mitsuba.load_dict({'type':'scene','shape_id':{...}})  (bake_shading.py:55-61).  Host SAH build + upload. */
-IRIS_API int iris_scene_create(const float *verts, int64_t nv, const int32_t *faces, int64_t nf, int device, int layout,
-                      iris_scene **out);
+IRIS_API int iris_scene_create(const float *verts, int64_t nv, const int32_t *faces, int64_t nf, int device, iris_scene **out);
 IRIS_API void iris_scene_destroy(iris_scene *);
 IRIS_API int iris_scene_get_info(const iris_scene *, iris_scene_info *out);
 
@@ -111,29 +110,25 @@ IRIS_API int iris_eval_emitter(const iris_emitter *, const iris_slf *, const flo
                       const float *roughness, float trace_roughness, int64_t B, float *Le, float *emit_pdf,
                       uint8_t *valid_next, iris_stream_t);
 
-/* Kernel variants of the fused bake (kernel-choice experiments; AUTO picks TILE_SORTED when a workspace is given) */
-enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED = 2 };
-
 /* ---- a3..a7 fused: the bake loop body (bake_shading.py:108-123 diffuse, :168-188 specular) -------------- */
 /* pos,nrm[,wo]: (P,3) records of the valid pixels.  u2: (P*spp,2) explicit uniforms in the reference's order
  * (row = pixel*spp + sample), or NULL -> in-kernel Philox4x32-10 keyed by (seed, pix_id[p]*spp+s, stream);
  * pix_id (P) int32 nullable (defaults to p) makes the sample set independent of how pixels are sharded.
- * Ld/Ls0/Ls1: (P,3) = mean over spp of Le, Le*g0, Le*g1.  tri_next (P*spp) int64 nullable debug output.
- * stats: nullable device uint64[16]; when given, an INSTRUMENTED (slower) build of the kernel adds {rays, BVH node
- * visits, triangle tests, wave-level node steps, wave-level triangle steps} to it (used to price the roofline).
+ * Ld/Ls0/Ls1: (P,3) = mean over spp of Le, Le*g0, Le*g1.  tri_next (P*spp) int64, nullable: the per-sample hit triangle
+ * (the reference's `triangle_idx` of ray_intersect, bake_shading.py:117 / :180).
  * workspace: device scratch of iris_bake_workspace_bytes() bytes for the tile-sorted kernel (8 tile-queue counters, the
  * workgroups' per-ray slots -- sampled direction, then hit -- and their traversal-stack overflow slabs; contents are
- * scratch, nothing survives the call); NULL selects the pixel-per-wave kernel.  Both give identical bits. */
+ * scratch, nothing survives the call); NULL (or spp > iris_bake_tile_max_spp()) selects the simpler pixel-per-wave kernel.  Both give
+ * identical bits. */
 IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular);   /* 0 if spp > iris_bake_tile_max_spp() */
 IRIS_API int iris_bake_tile_max_spp(void);   /* largest spp the tile-sorted / view kernels take (5120: the LDS ray list) */
 IRIS_API int iris_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                       int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,
-                      float *Ld, int64_t *tri_next, uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes,
-                      iris_stream_t);
+                      float *Ld, int64_t *tri_next, void *workspace, uint64_t workspace_bytes, iris_stream_t);
 IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                        const float *wo, float roughness, int64_t P, int spp, const float *u2, uint64_t seed,
                        uint32_t stream_id, const int32_t *pix_id, float *Ls0, float *Ls1, int64_t *tri_next,
-                       uint64_t *stats, int variant, void *workspace, uint64_t workspace_bytes, iris_stream_t);
+                       void *workspace, uint64_t workspace_bytes, iris_stream_t);
 
 /* All lobes of one view (bake_shading.py:93-204) in ONE launch with one tile queue: n_lobes <= 8; roughness[l] < 0 selects the
  * diffuse lobe (out1[l] may be NULL), otherwise the specular lobe of that roughness; spp[l] <= iris_bake_tile_max_spp(); Philox uniforms only.

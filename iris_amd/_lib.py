@@ -25,7 +25,8 @@ _P, _I64, _I32, _F, _D, _U64, _U32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, 
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 PROTOTYPES = {
-    "iris_scene_create": [_P, _I64, _P, _I64, _I32, _I32, C.POINTER(_P)],
+    "iris_scene_create": [_P, _I64, _P, _I64, _I32, C.POINTER(_P)],
+    "iris_debug_scene_create": [_P, _I64, _P, _I64, _I32, _I32, C.POINTER(_P)],
     "iris_scene_destroy": [_P],
     "iris_scene_get_info": [_P, C.POINTER(SceneInfo)],
     "iris_slf_create": [_P, _I32, _P, _I64, _D, _D, _I32, C.POINTER(_P)],
@@ -41,8 +42,11 @@ PROTOTYPES = {
     "iris_slf_lookup": [_P, _P, _I64, _P, _P, _P],
     "iris_eval_emitter": [_P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P],
     "iris_bake_workspace_bytes": [_I64, _I32, _I32],
-    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _I32, _P, _U64, _P],
-    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
+    "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _U64, _P],
+    "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _U64, _P],
+    "iris_debug_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
+    "iris_debug_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
+    "iris_debug_set": [C.c_char_p, C.c_longlong],
     "iris_bake_view": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _U64, _P, _P, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
@@ -91,6 +95,11 @@ def lib():
             fn.restype = _RESTYPE.get(name, C.c_int)
         _lib = l
     return _lib
+
+
+def debug_set(key, value):
+    """iris_debug_set (include/iris_hip_debug.h): process-wide tuning option; value < 0 restores the default."""
+    check(lib().iris_debug_set(key.encode(), int(value)))
 
 
 def check(rc):

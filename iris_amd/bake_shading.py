@@ -52,36 +52,51 @@ def _workspace(P, spp, specular, variant, dev):
     return torch.empty(n, device=dev, dtype=torch.uint8), n
 
 
-def bake_diffuse(scene, emitter, position, normal, spp=SPP_DIFFUSE, u2=None, seed=0, stream_id=0, pix_id=None, want_tri=False, stats=None,
-                 variant=L.BAKE_AUTO):
+def bake_diffuse(scene, emitter, position, normal, spp=SPP_DIFFUSE, u2=None, seed=0, stream_id=0, pix_id=None, want_tri=False, want_src=False,
+                 stats=None, variant=L.BAKE_AUTO):
     """Ld_ of bake_shading.py:108-123 for all P valid pixels: mean over spp of Le along cosine-sampled rays.
     u2: optional (P*spp,2) uniforms in the reference's order (parity mode); otherwise in-kernel Philox.
-    stats: optional zeroed int64[8] device tensor -> instrumented launch (rays, node visits, tri tests, ...)."""
+    want_tri: also return the per-sample hit triangle (P*spp,) int64.
+    Diagnostics (routed through include/iris_hip_debug.h): want_src -> per-sample radiance-table row; stats -> zeroed int64[16]
+    device tensor for an instrumented launch; variant -> a specific kernel.  Returns Ld [, tri] [, src]."""
     position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
     Ld = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    src = torch.empty(P * spp, device=dev, dtype=torch.int64) if want_src else None
     ws, ws_bytes = _workspace(P, spp, False, variant, dev)
     with torch.cuda.device(dev):
-        L.check(L.lib().iris_bake_diffuse(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal),
-                                          P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ld), L.ptr(tri), L.ptr(stats),
-                                          int(variant), L.ptr(ws), ws_bytes, L.stream()))
-    return (Ld, tri) if want_tri else Ld
+        if want_src or stats is not None or variant != L.BAKE_AUTO:
+            L.check(L.lib().iris_debug_bake_diffuse(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal),
+                                                    P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ld), L.ptr(tri), L.ptr(src),
+                                                    L.ptr(stats), int(variant), L.ptr(ws), ws_bytes, L.stream()))
+        else:
+            L.check(L.lib().iris_bake_diffuse(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal),
+                                              P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ld), L.ptr(tri),
+                                              L.ptr(ws), ws_bytes, L.stream()))
+    res = (Ld,) + ((tri,) if want_tri else ()) + ((src,) if want_src else ())
+    return res if len(res) > 1 else Ld
 
 
-def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None, seed=0, stream_id=1, pix_id=None, want_tri=False,
+def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None, seed=0, stream_id=1, pix_id=None, want_tri=False, want_src=False,
                   stats=None, variant=L.BAKE_AUTO):
-    """Ls0_, Ls1_ of bake_shading.py:168-188 for one roughness level."""
+    """Ls0_, Ls1_ of bake_shading.py:168-188 for one roughness level.  Returns Ls0, Ls1 [, tri] [, src] (see bake_diffuse)."""
     position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
     wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
     if isinstance(roughness, torch.Tensor):
         roughness = float(roughness.detach().float().cpu().item())
     Ls0 = torch.empty(P, 3, device=dev, dtype=torch.float32)
     Ls1 = torch.empty(P, 3, device=dev, dtype=torch.float32)
+    src = torch.empty(P * spp, device=dev, dtype=torch.int64) if want_src else None
     ws, ws_bytes = _workspace(P, spp, True, variant, dev)
     with torch.cuda.device(dev):
-        L.check(L.lib().iris_bake_specular(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo),
-                                           roughness, P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ls0), L.ptr(Ls1),
-                                           L.ptr(tri), L.ptr(stats), int(variant), L.ptr(ws), ws_bytes, L.stream()))
-    return (Ls0, Ls1, tri) if want_tri else (Ls0, Ls1)
+        if want_src or stats is not None or variant != L.BAKE_AUTO:
+            L.check(L.lib().iris_debug_bake_specular(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo),
+                                                     roughness, P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ls0), L.ptr(Ls1),
+                                                     L.ptr(tri), L.ptr(src), L.ptr(stats), int(variant), L.ptr(ws), ws_bytes, L.stream()))
+        else:
+            L.check(L.lib().iris_bake_specular(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo),
+                                               roughness, P, int(spp), L.ptr(u2), int(seed), int(stream_id), L.ptr(pix_id), L.ptr(Ls0), L.ptr(Ls1),
+                                               L.ptr(tri), L.ptr(ws), ws_bytes, L.stream()))
+    return (Ls0, Ls1) + ((tri,) if want_tri else ()) + ((src,) if want_src else ())
 
 
 def bake_lobes(scene, emitter, position, normal, wo, roughness, spps, seed=0, stream_ids=None, pix_id=None):
@@ -110,6 +125,11 @@ def bake_lobes(scene, emitter, position, normal, wo, roughness, spps, seed=0, st
         L.check(L.lib().iris_bake_view(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(pix_id),
                                        P, n, rough, spp_a, sid, int(seed), p0, p1, L.ptr(ws), ws_bytes, L.stream()))
     return [outs0[l] if roughness[l] is None else (outs0[l], outs1[l]) for l in range(n)]
+
+
+def view_seed(seed, im_id):
+    """Philox key of view `im_id` for a run seeded with `seed` (64-bit golden-ratio mix; im_id 0 keeps the plain seed)."""
+    return (int(seed) + int(im_id) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
 
 class LobeStreams:
@@ -302,7 +322,9 @@ def main(argv=None):
         if not args.overwrite and all(os.path.exists(f) for f in files):
             continue
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
-        out = bake_view(scene, emitter, xs, ds, args.spp_diffuse, args.spps_specular, seed=args.seed, image_width=img_hw[1], denoiser=denoiser)
+        # per-view Philox key: the reference's torch.rand stream advances from view to view, so its Monte-Carlo noise is independent
+        # across the training views; keyed on the view id (not on the rank), so that results do not depend on how views are sharded
+        out = bake_view(scene, emitter, xs, ds, args.spp_diffuse, args.spps_specular, seed=view_seed(args.seed, im_id), image_width=img_hw[1], denoiser=denoiser)
         rays += out["rays"]
         # 13 maps -> host once, then the files are compressed and written by a thread pool while the next view bakes (zlib and numpy
         # release the GIL; a 1080p ZIP map costs ~1 s of CPU, the bake of the whole view 0.3 s of GPU).  Files appear under their final

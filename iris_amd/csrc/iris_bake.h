@@ -19,8 +19,9 @@ struct BakeArgs {
     const float* u2; const int32_t* pix_id;
     int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
     float* out0; float* out1; int64_t* tri_next;
+    int64_t* src_next;          // diagnostics (iris_hip_debug.h): per sample, the radiance-table row that was read (eval_emitter1's src)
     unsigned long long* stats;  // instrumented launches only: 16 slots {rays, node visits, tri tests, wave node iters, wave leaf iters, rays with
-                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, ...}
+                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, [11..14] node visits with index < 21 / 85 / 341 / 1365}
     // tile kernels only
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
@@ -81,8 +82,9 @@ __device__ __forceinline__ RayOut trace_shade(const BakeArgs& a, int64_t p, int 
     }
     if (a.tri_next) a.tri_next[p * a.spp + s] = tri;
     // eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0)  (bake_shading.py:121-122, :184-185)
-    float epdf; bool vn;
-    f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
+    float epdf; bool vn; int src;
+    f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn, src);
+    if (a.src_next) a.src_next[p * a.spp + s] = src;
     RayOut r;
     if (SPEC) { r.r0 = Le.x * g0; r.g0 = Le.y * g0; r.b0 = Le.z * g0; r.r1 = Le.x * g1; r.g1 = Le.y * g1; r.b1 = Le.z * g1; }
     else { r.r0 = Le.x; r.g0 = Le.y; r.b0 = Le.z; r.r1 = r.g1 = r.b1 = 0.f; }
@@ -111,6 +113,12 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
             uint32_t x = w[k];
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 9 + k, (unsigned long long)x);
+        }
+        uint32_t tp[4] = {ts.top21, ts.top85, ts.top341, ts.top1365};
+        for (int k = 0; k < 4; ++k) {
+            uint32_t x = tp[k];
+            for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+            if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 11 + k, (unsigned long long)x);
         }
         unsigned long long y = ts.max_steps64;
         for (int m = 1; m < 64; m <<= 1) y += __shfl_xor(y, m);
@@ -171,6 +179,9 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU): 7 x 20 488 B of LDS, 72 VGPRs.
 #define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s
 #endif
+#ifndef IRIS_LDS_NODES           // top-of-tree nodes staged in LDS per workgroup (80 B each; 0 = none).  21 = 3 levels of a full BVH4, 85 = 4, 341 = 5
+#define IRIS_LDS_NODES 0
+#endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
 #define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
 #endif
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 //   once per tile and was measured 9 % slower per fence pair).
 template <bool SPEC, bool COUNT, int LAYOUT, int TILE_STACK>
 __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
-                                          uint32_t* ovf, TraceStats& ts, uint32_t& n_rays) {
+                                          uint32_t* ovf, const uint4* s_top, TraceStats& ts, uint32_t& n_rays) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
     float2* res_g = reinterpret_cast<float2*>(res + kTileRays);   // GGX weights (g1, g0): second array of the slab
@@ -199,8 +210,8 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     const int nr = np * spp;
 
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
-    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
-        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
+    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true, IRIS_LDS_NODES>(
+        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, s_top, ts,
         [&](int r) -> uint32_t {
             const int pl = r / spp, s = r - pl * spp;
             const int64_t p = p0 + pl;
@@ -247,8 +258,9 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
                     tri = __float_as_int(tc.y);
                 }
                 if (a.tri_next) a.tri_next[(p0 + pl) * spp + s] = tri;
-                float epdf; bool vn;
-                const f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn);
+                float epdf; bool vn; int src;
+                const f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn, src);
+                if (a.src_next) a.src_next[(p0 + pl) * spp + s] = src;
                 if (SPEC) {
                     const float2 qb = res_g[pl * spp + s];   // (g1, g0)
                     a0x += Le.x * qb.y; a0y += Le.y * qb.y; a0z += Le.z * qb.y;
@@ -289,14 +301,20 @@ __device__ __forceinline__ long long claim_tile(unsigned int* counters, long lon
     return n_tiles;
 }
 
+// The instrumented (COUNT) instantiations are compiled for 4 waves/SIMD instead of IRIS_TILE_WAVES: the counters need ~25 more live
+// registers, and at 72 VGPRs hipcc 7.2 spilled 73 of them and (round 1, commit 6b44483) produced stack-depth counters that differed
+// from the pixel-per-wave kernel's -- per-ray quantities that cannot depend on the schedule (tests/test_stats.py asserts their equality).
+// Counts do not depend on occupancy; the grid and the workspace stay those of the production kernel.
 template <bool SPEC, bool COUNT, int LAYOUT>
-__global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
+__global__ __launch_bounds__(kBlock, COUNT ? 4 : IRIS_TILE_WAVES) void bake_tile_kernel(BakeArgs a) {
     constexpr int kTileStack = IRIS_TILE_STACK;  // 10240 B ray list + kTileStack KiB stacks + 12 B must fit 160 KiB / IRIS_TILE_WAVES
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
+    __shared__ uint4 s_top[IRIS_LDS_NODES > 0 ? IRIS_LDS_NODES * kLdsNodeQuads : 1];
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
+    if (IRIS_LDS_NODES > 0) stage_top_nodes(a.sc, s_top, IRIS_LDS_NODES);   // published by the first barrier of the tile loop
     constexpr int NC = SPEC ? 2 : 1;
     float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
     uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform (Stack adds the lane)
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_tile_kernel(Bake
         __syncthreads();
         const int64_t tile = s_tile;
         if (tile >= n_tiles) break;
-        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
+        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, s_top, ts, n_rays);
     }
     flush_stats<COUNT>(a, ts, n_rays);
 }
@@ -336,8 +354,10 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
+    __shared__ uint4 s_top[IRIS_LDS_NODES > 0 ? IRIS_LDS_NODES * kLdsNodeQuads : 1];
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
+    if (IRIS_LDS_NODES > 0) stage_top_nodes(v.base.sc, s_top, IRIS_LDS_NODES);   // published by the first barrier of the tile loop
     float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
     uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform; no private scratch in this kernel
     for (;;) {
@@ -351,10 +371,10 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
         for (int k = 1; k < v.n_lobes; ++k) if (gt >= v.lobe[k].tile_begin) l = k;   // wave-uniform
         BakeArgs a = v.base;
         a.spp = v.lobe[l].spp; a.rough = v.lobe[l].rough; a.stream_id = v.lobe[l].stream_id; a.tile_px = v.lobe[l].tile_px;
-        a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr;
+        a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr; a.src_next = nullptr;
         TraceStats ts; uint32_t n_rays = 0;   // unused (COUNT = false)
-        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
-        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
+        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, s_top, ts, n_rays);
+        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, s_top, ts, n_rays);
     }
 }
 

@@ -163,34 +163,44 @@ __device__ __forceinline__ int slf_index(const SlfDev& s, f3 p) {
     int cx = voxel_coord(p.x, s), cy = voxel_coord(p.y, s), cz = voxel_coord(p.z, s);
     return s.inds[((int64_t)cz * s.H + cy) * s.H + cx];
 }
-// model/slf.py:63-70 forward
-__device__ __forceinline__ f3 slf_forward(const SlfDev& s, f3 p) {
-    int j = slf_index(s, p);
+// model/slf.py:63-70 forward   (j: the voxel row that was read, -1 = empty space)
+__device__ __forceinline__ f3 slf_forward(const SlfDev& s, f3 p, int& j) {
+    j = slf_index(s, p);
     if (j < 0) return mk3(0.f, 0.f, 0.f);
     float4 r = s.radiance[j];
     return mk3(r.x, r.y, r.z);
 }
+__device__ __forceinline__ f3 slf_forward(const SlfDev& s, f3 p) { int j; return slf_forward(s, p, j); }
 // model/emitter.py:180-221 eval_emitter, one sample.  tri = original triangle index or -1.
+// src (diagnostics): which table row the radiance came from: -2 - emitter ordinal for an emitter triangle, the VoxelSLF row for the
+// radiance cache, -1 for empty space / a miss / no lookup.
 __device__ __forceinline__ f3 eval_emitter1(const EmitDev& e, const SlfDev& s, f3 p, int64_t tri, bool has_rough,
-                                            float rough, float trace_rough, float& emit_pdf, bool& valid_next) {
+                                            float rough, float trace_rough, float& emit_pdf, bool& valid_next, int& src) {
     bool vis = tri != -1;
     f3 Le = mk3(0.f, 0.f, 0.f);
     emit_pdf = 0.f;
     int ord = -1;
     if (vis) ord = e.emit_ord[tri < 0 ? tri + e.nf : tri];
     bool is_area = ord >= 0;
+    src = -1;
     if (is_area) {
+        src = -2 - ord;
         float4 r = e.radiance[ord];
         Le = mk3(r.x, r.y, r.z);
         emit_pdf = e.emitter_pdf / fmaxf(e.area[ord], 1e-12f);
     }
     valid_next = (!is_area) && vis;
     if (has_rough && (!is_area) && vis && rough > trace_rough) {
-        f3 d = slf_forward(s, p);
+        f3 d = slf_forward(s, p, src);
         Le = mk3(Le.x + d.x, Le.y + d.y, Le.z + d.z);
         if ((d.x + d.y) + d.z > 0.f) valid_next = false;
     }
     return Le;
+}
+__device__ __forceinline__ f3 eval_emitter1(const EmitDev& e, const SlfDev& s, f3 p, int64_t tri, bool has_rough,
+                                            float rough, float trace_rough, float& emit_pdf, bool& valid_next) {
+    int src;
+    return eval_emitter1(e, s, p, tri, has_rough, rough, trace_rough, emit_pdf, valid_next, src);
 }
 
 }  // namespace iris

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/iris_hip.h"
+#include "../../include/iris_hip_debug.h"
 #include "bvh_build.h"
 #include "iris_device.h"
 #include "iris_trace.h"
@@ -37,6 +38,20 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     catch (...) { return fail(IRIS_ERR_BUILD, "unknown C++ exception"); }
 
 extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
+
+// ---- diagnostics options (iris_hip_debug.h): process-wide, set by tests / experiments only; -1 = the built-in default
+static long long g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1;
+extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
+    if (!key) return fail(IRIS_ERR_ARG, "iris_debug_set: null key");
+    const std::string k(key);
+    if (k == "bvh_max_leaf") g_opt_bvh_max_leaf = value;
+    else if (k == "phase_min") g_opt_phase_min = value;
+    else if (k == "tile_target_rays") g_opt_tile_target_rays = value;
+    else if (k == "tiles_per_block") g_opt_tiles_per_block = value;
+    else if (k == "pt_tile_min") g_opt_pt_tile_min = value;
+    else return fail(IRIS_ERR_ARG, "iris_debug_set: unknown option " + k);
+    return IRIS_OK;
+}
 extern "C" IRIS_API const char* iris_version(void) { return "iris_hip 0.1 (gfx950)"; }
 
 // ======================================================================================================
@@ -88,8 +103,11 @@ static int num_cus() {
 }
 
 // ------------------------------------------------------------------------------------------------------
-extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int device, int layout,
-                                 iris_scene** out) {
+extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int device, iris_scene** out) {
+    return iris_debug_scene_create(verts, nv, faces, nf, device, IRIS_BVH_DEFAULT, out);
+}
+extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int device, int layout,
+                                       iris_scene** out) {
     API_BEGIN
     if (!out || nv < 0 || nf < 0 || (nf > 0 && (!verts || !faces))) return fail(IRIS_ERR_ARG, "iris_scene_create: bad arguments");
     if (nf >= (1 << 26)) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^26 triangles (32-bit byte offsets into the 64-B records)");
@@ -100,7 +118,7 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
     HIP_TRY(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     int max_leaf = 4;
-    if (const char* e = getenv("IRIS_BVH_MAX_LEAF")) max_leaf = std::min(7, std::max(1, atoi(e)));   // tuning knob
+    if (g_opt_bvh_max_leaf > 0) max_leaf = (int)std::min<long long>(7, g_opt_bvh_max_leaf);   // iris_debug_set("bvh_max_leaf")
     WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf);
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
 
@@ -189,9 +207,9 @@ extern "C" IRIS_API int iris_scene_create(const float* verts, int64_t nv, const 
     s->dev.n_tris = (int)nt;
     s->dev.layout = layout == IRIS_BVH4_Q8 ? kLayoutQ8 : kLayoutF32;
     s->dev.phase_min = kPhaseMin;
-    if (const char* e = getenv("IRIS_PHASE_MIN")) s->dev.phase_min = atoi(e);  // tuning knob (results do not depend on it)
+    if (g_opt_phase_min >= 0) s->dev.phase_min = (int)g_opt_phase_min;  // iris_debug_set("phase_min") (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
-    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth; s->info.lds_nodes = 0;
+    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth; s->info.lds_nodes = layout == IRIS_BVH4_Q8 ? IRIS_LDS_NODES : 0;
     s->info.sah_cost = bvh.sah_cost;
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
@@ -625,9 +643,9 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // Pixels per tile.  ~5000-ray tiles are the optimum at 1080p x SPP 128 (with 32-B slots: 8192 rays: 324 ms per view, 6144: 322, 5120: 319,
 // 4096: 308, 3072: 314, 2048: 326; with today's 24-B slots 4096: 6.99, 5120: 7.04, 6144: 6.98 Grays/s): larger tiles push the workgroups' slot
 // slabs out of the 256 MB Infinity Cache, smaller ones pay more low-utilisation drains (one per wave and tile).  The LDS ray list is sized for
-// exactly that (kTileRays = 5120), which is what lets 7 workgroups share a CU.  IRIS_TILE_TARGET_RAYS overrides downwards (tuning knob).
+// exactly that (kTileRays = 5120), which is what lets 7 workgroups share a CU.  iris_debug_set("tile_target_rays") overrides downwards.
 static int tile_pixels(int spp) {
-    static const int target = [] { const char* e = getenv("IRIS_TILE_TARGET_RAYS"); return e ? std::min(kTileRays, std::max(64, atoi(e))) : kTileRays; }();
+    const int target = g_opt_tile_target_rays > 0 ? (int)std::min<long long>(kTileRays, std::max<long long>(64, g_opt_tile_target_rays)) : kTileRays;
     return std::max(1, std::min(kTileRays, std::max(target, spp)) / spp);
 }
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
@@ -648,7 +666,7 @@ extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int s
 
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                        const float* wo, float rough, int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id,
-                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, uint64_t* stats, int variant,
+                       const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, int64_t* src_next, uint64_t* stats, int variant,
                        void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
     if (!sc || !em || !slf || P < 0 || spp < 1 || (P > 0 && (!pos || !nrm || !out0 || (spec && (!wo || !out1)))))
         return fail(IRIS_ERR_ARG, "iris_bake: bad arguments");
@@ -658,7 +676,7 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     a.sc = sc->dev; a.em = em->dev; a.slf = slf->dev;
     a.pos = pos; a.nrm = nrm; a.wo = wo; a.u2 = u2; a.pix_id = pix_id;
     a.P = P; a.spp = spp; a.seed = seed; a.stream_id = stream_id; a.rough = rough;
-    a.out0 = out0; a.out1 = out1; a.tri_next = tri_next; a.stats = (unsigned long long*)stats;
+    a.out0 = out0; a.out1 = out1; a.tri_next = tri_next; a.src_next = src_next; a.stats = (unsigned long long*)stats;
     const uint64_t need = iris_bake_workspace_bytes(P, spp, spec ? 1 : 0);
     bool tiled = variant != IRIS_BAKE_PIXEL_PER_WAVE && need > 0 && workspace && workspace_bytes >= need;
     if (variant == IRIS_BAKE_TILE_SORTED && !tiled)
@@ -668,7 +686,7 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         const int blocks = bake_grid_blocks();
         int tile_px = tile_pixels(spp);                      // ~4096 rays per tile (at most what fits the LDS ray list) ...
         int tiles_per_block = 4;                             // ... but at least ~4 tiles per workgroup, so that the dynamic tile queue
-        if (const char* e = getenv("IRIS_TILES_PER_BLOCK")) tiles_per_block = std::max(1, atoi(e));   // balances (tuning knob)
+        if (g_opt_tiles_per_block > 0) tiles_per_block = (int)g_opt_tiles_per_block;                  // balances (iris_debug_set("tiles_per_block"))
         const int64_t even = (P + (int64_t)blocks * tiles_per_block - 1) / ((int64_t)blocks * tiles_per_block);
         if (even < tile_px) tile_px = (int)std::max<int64_t>(even, std::min(tile_px, 16));   // not below 16 px: the sort needs rays
         if (tile_px < 1) tile_px = 1;
@@ -746,16 +764,30 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
 }
 extern "C" IRIS_API int iris_bake_diffuse(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                                  int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id, const int32_t* pix_id,
-                                 float* Ld, int64_t* tri_next, uint64_t* stats, int variant, void* workspace, uint64_t workspace_bytes,
-                                 iris_stream_t stream) {
-    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, stats, variant,
-                       workspace, workspace_bytes, stream);
+                                 float* Ld, int64_t* tri_next, void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
+    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, nullptr, nullptr,
+                       IRIS_BAKE_AUTO, workspace, workspace_bytes, stream);
 }
 extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                                   const float* wo, float roughness, int64_t P, int spp, const float* u2, uint64_t seed,
                                   uint32_t stream_id, const int32_t* pix_id, float* Ls0, float* Ls1, int64_t* tri_next,
-                                  uint64_t* stats, int variant, void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
-    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, stats, variant,
+                                  void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
+    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, nullptr, nullptr,
+                       IRIS_BAKE_AUTO, workspace, workspace_bytes, stream);
+}
+// diagnostics twins (iris_hip_debug.h): kernel variant, instrumented build, per-sample source rows
+extern "C" IRIS_API int iris_debug_bake_diffuse(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
+                                       int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id, const int32_t* pix_id,
+                                       float* Ld, int64_t* tri_next, int64_t* src_next, uint64_t* stats, int variant, void* workspace,
+                                       uint64_t workspace_bytes, iris_stream_t stream) {
+    return bake_launch(false, sc, em, slf, pos, nrm, nullptr, -1.f, P, spp, u2, seed, stream_id, pix_id, Ld, nullptr, tri_next, src_next, stats, variant,
+                       workspace, workspace_bytes, stream);
+}
+extern "C" IRIS_API int iris_debug_bake_specular(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
+                                        const float* wo, float roughness, int64_t P, int spp, const float* u2, uint64_t seed,
+                                        uint32_t stream_id, const int32_t* pix_id, float* Ls0, float* Ls1, int64_t* tri_next, int64_t* src_next,
+                                        uint64_t* stats, int variant, void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
+    return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, src_next, stats, variant,
                        workspace, workspace_bytes, stream);
 }
 
@@ -763,11 +795,11 @@ extern "C" IRIS_API int iris_bake_specular(const iris_scene* sc, const iris_emit
 // a9 (cfg 5): path_tracing_single building blocks and stages (iris_pt.h)
 // ======================================================================================================
 // Large batches go through the direction-sorted, persistent-lane tile kernel (iris_pt.h); small ones (cfg 5: 262 144 rays) keep the
-// one-ray-per-thread kernels, which expose more parallelism.  IRIS_PT_TILE_MIN overrides the switch-over (tests force the tile path).
+// one-ray-per-thread kernels, which expose more parallelism.  iris_debug_set("pt_tile_min") overrides the switch-over (tests force the tile path).
 static bool pt_tiling(int64_t N, int& tile_rays, int& grid) {
     const int64_t blocks = (int64_t)num_cus() * IRIS_PT_WAVES;
     int64_t min_n = 512 * blocks;
-    if (const char* e = getenv("IRIS_PT_TILE_MIN")) min_n = atoll(e);
+    if (g_opt_pt_tile_min >= 0) min_n = g_opt_pt_tile_min;
     if (N < min_n) return false;
     int64_t t = (N / (2 * blocks) + kBlock - 1) / kBlock * kBlock;          // >= 2 tiles per resident workgroup ...
     tile_rays = (int)std::min<int64_t>(kPtTileCap, std::max<int64_t>(kBlock, t));   // ... of 256 .. 4096 rays

@@ -24,6 +24,17 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     return m;
 }
 
+// Copies the first n nodes (64-B records, breadth-first order: the top levels of the tree) into LDS at an 80-B stride.  Once per
+// persistent workgroup; the caller's first barrier publishes them.
+__device__ __forceinline__ void stage_top_nodes(const SceneDev& sc, uint4* s_top, int n) {
+    const int have = min(n, sc.n_nodes);
+    for (int i = threadIdx.x; i < n * 4; i += kBlock) {
+        const int node = i >> 2, q = i & 3;
+        // nodes the tree does not have are never referenced; fill them with an all-miss node anyway
+        s_top[node * kLdsNodeQuads + q] = node < have ? reinterpret_cast<const uint4*>(sc.nodes)[i] : make_uint4(0u, 0u, 0xffffffffu, q == 3 ? 0xffffffffu : 0u);
+    }
+}
+
 // LDS contract: s_sorted[CAP] (uint16 ray list), s_stack[TILE_STACK * 256] (traversal stacks; doubles as the sort's key / histogram /
 // cursor storage: CAP bytes of keys, then 256 + 256 words -- the uses are separated by workgroup barriers), *s_chunk (cursor).
 // Before the call the caller has zeroed the histogram (s_stack + CAP/4, 256 words) and *s_chunk and passed a barrier.
@@ -34,9 +45,10 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
 // Everything exchanged through global memory here stays inside ONE workgroup, so __syncthreads() orders it (the waves of a
 // workgroup share their CU's write-through L1; an agent-scope __threadfence() would flush that L1 -- including the hot upper BVH
 // levels -- once per tile and was measured 9 % slower per fence pair).  Ends with a barrier: hits are visible to the caller.
-template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, class PhaseA, class FetchRay, class Prepare, class Retire>
+//   s_top (LDS_NODES > 0)       : the first LDS_NODES nodes staged in LDS by stage_top_nodes()
+template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, int LDS_NODES, class PhaseA, class FetchRay, class Prepare, class Retire>
 __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk, uint32_t* ovf,
-                                                TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare, Retire retire) {
+                                                const uint4* s_top, TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare, Retire retire) {
     static_assert(TILE_STACK * kBlock * 4 >= CAP + 2 * 256 * 4, "stack region too small to alias the sort keys");
     uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
     uint32_t* s_hist = s_stack + CAP / 4;
@@ -79,7 +91,7 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
             return true;
         };
         auto ret = [&](const Hit& h) { retire(my_r, h); };
-        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc, s_stack + tid, ovf, &ts, fetch, prepare, ret);
+        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF, LDS_NODES>(sc, s_stack + tid, ovf, s_top, &ts, fetch, prepare, ret);
     }
     __syncthreads();
 }

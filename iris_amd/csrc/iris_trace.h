@@ -36,8 +36,14 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
 // (scratch) array or -- GLOBAL_OVF, kernels that must not use scratch -- in a workgroup-private slab of the caller's workspace
 // laid out [entry][thread] so that the rare accesses coalesce.
 constexpr int kStackCapacity = kStackLds + kStackSpill;
-template <int LDS_DEPTH, bool GLOBAL_OVF = false>
+// LDS_NODES > 0: the first LDS_NODES nodes of the table (breadth-first order = the top of the tree, visited by every ray) are staged in
+// LDS as kLdsNodeStride-byte records (`top`); node_step reads them with ds_read_b128 instead of going through the vector-memory path.
+constexpr int kLdsNodeQuads = 5;   // 64-B node + 16 B of padding: an 80-B stride spreads lane-divergent ds_read_b128 over the banks
+                                   // (tools/microbench: 8.0 cycles per read against 16.3 at a 64-B stride, 16 waves per CU, one lane per node)
+template <int LDS_DEPTH, bool GLOBAL_OVF = false, int LDS_NODES = 0>
 struct Stack {
+    static constexpr int kLdsNodes = LDS_NODES;
+    const uint4* top;  // LDS_NODES > 0: the staged nodes
     uint32_t* lds;  // &s_stack[threadIdx.x]
     uint32_t* ovf;  // GLOBAL_OVF: the workgroup's slab (wave-uniform: stays in scalar registers; the lane offset is added at the rare use)
     uint32_t spill[GLOBAL_OVF ? 1 : kStackCapacity - LDS_DEPTH];
@@ -81,8 +87,23 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 
 // BVH4_F32 traversal: node = {lox[4],hix[4],loy[4],hiy[4],loz[4],hiz[4],ref[4],pad[4]} (128 B, one L2 line).
 // ref: internal -> node index; leaf -> 0x80000000 | start<<3 | count; unused slot -> inverted box (never hit).
 // -------------------------------------------------------------------------------------------------------
+// Selects through an explicit SGPR-pair lane mask.  Measured (tools/microbench, 7 waves/SIMD): v_cndmask_b32_e64 with an SGPR-pair mask
+// issues at the ordinary 4-cycle rate (548 G wave-inst/s chip-wide), the VOP2 form that reads VCC implicitly at 108 G/s (~20 cycles), 6-7
+// cycles when VCC was written just before.  hipcc picks VCC for about half of the selects of node_step; these helpers pin the mask form.
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t m_le(float a, float b) { lanemask_t m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ lanemask_t m_lt(float a, float b) { lanemask_t m; asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ float m_sel(lanemask_t m, float x, float y) { float r; asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(x), "v"(y), "s"(m)); return r; }          // m ? x : y
+__device__ __forceinline__ uint32_t m_sel(lanemask_t m, uint32_t x, uint32_t y) { uint32_t r; asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(x), "v"(y), "s"(m)); return r; }
+#ifdef IRIS_SEL_ASM
+#define IRIS_CE(ka, ra, kb, rb) { const lanemask_t sw = m_lt(kb, ka); const float tk = m_sel(sw, kb, ka); kb = m_sel(sw, ka, kb); ka = tk; \
+                                  const uint32_t tr = m_sel(sw, rb, ra); rb = m_sel(sw, ra, rb); ra = tr; }
+#define IRIS_HITKEY(tn, tf) m_sel(m_le(tn, tf), tn, INFINITY)
+#else
 #define IRIS_CE(ka, ra, kb, rb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                   uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
+#define IRIS_HITKEY(tn, tf) ((tn) <= (tf) ? (tn) : INFINITY)
+#endif
 
 // Traversal statistics (instrumented builds only): per-lane counts, reduced by the caller.
 struct TraceStats {
@@ -93,6 +114,9 @@ struct TraceStats {
     uint32_t sp_gt8 = 0, sp_gt12 = 0, sp_gt16 = 0;  // rays whose stack ever exceeded 8 / 12 / 16 entries
     unsigned long long max_steps64 = 0;             // sum over wave-chunks of 64 * (longest ray of the chunk, in node+triangle steps)
     uint32_t drain_nodes = 0, drain_node_iters = 0; // trace_stream: the same two node counters while the ray list is exhausted (no refill)
+    uint32_t top21 = 0, top85 = 0, top341 = 0, top1365 = 0;   // node visits with node index < 21 / 85 / 341 / 1365 (nodes are in breadth-first order:
+                                                              // the first 1 + 4 + 16 (+ 64 (+ 256 (+ 1024))) nodes are the top 3 (4, 5, 6) levels of a full tree)
+    __device__ __forceinline__ void count_top(uint32_t cur) { top21 += cur < 21u; top85 += cur < 85u; top341 += cur < 341u; top1365 += cur < 1365u; }
 };
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
@@ -138,8 +162,14 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
     const bool px = r.px, py = r.py, pz = r.pz;
     if (LAYOUT == kLayoutQ8) {
         // 32-bit byte offset from the (scalar) table base: one shift instead of a 64-bit shift + add per visit (the node table is < 4 GB)
-        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
-        const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
+        uint4 hd, q1, q2, rf;
+        if (STACK::kLdsNodes > 0 && r.cur < (uint32_t)STACK::kLdsNodes) {
+            const uint4* n = st.top + r.cur * kLdsNodeQuads;
+            hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3];
+        } else {
+            const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
+            hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3];
+        }
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
         // per-axis: t(q) = q * 2^e * idir + (origin * idir - o * idir); the node stores 2^(e+24) as a float (see below)
         const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
@@ -153,13 +183,25 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // rounded once by the FMA: the same t as before, bit for bit.
         typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
 #define IRIS_PLANES(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
+#ifdef IRIS_SLAB_CVT
+        // A/B: byte -> float conversions (v_cvt_f32_ubyteN) + plain v_fma_f32 (double-rate on gfx950) instead of v_perm + v_fma_mix.
+        // fma((float)q, rnd(2^e * idir), b): the same real number rounded once, so the same t bit for bit (2^-24 scaling is exact).
+        const float cx = ax * 5.9604644775390625e-08f, cy = ay * 5.9604644775390625e-08f, cz = az * 5.9604644775390625e-08f;
+#define IRIS_SLABQ(K, C)                                                                                                          \
+    {                                                                                                                             \
+        float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), cx, bx), fmaf(ubyte(nyq, C), cy, by)), fmaxf(fmaf(ubyte(nzq, C), cz, bz), 0.f)); \
+        float tf = fminf(fminf(fmaf(ubyte(fxq, C), cx, bx), fmaf(ubyte(fyq, C), cy, by)), fminf(fmaf(ubyte(fzq, C), cz, bz), r.h.t)); \
+        K = IRIS_HITKEY(tn, tf);                                                                                                  \
+    }
+#else
 #define IRIS_SLABQ(K, C)                                                                                                          \
     {                                                                                                                             \
         const iris_h2 hx = IRIS_PLANES(nxq, fxq, C), hy = IRIS_PLANES(nyq, fyq, C), hz = IRIS_PLANES(nzq, fzq, C);                 \
         float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
         float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
-        K = tn <= tf ? tn : INFINITY;                                                                                             \
+        K = IRIS_HITKEY(tn, tf);                                                                                                  \
     }
+#endif
         IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
 #undef IRIS_SLABQ
 #undef IRIS_PLANES
@@ -203,7 +245,7 @@ template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
     RayState r;
     ray_begin(r, o, d);
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.top = nullptr; st.sp = 0;
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
@@ -214,7 +256,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
             if (n_node == 0) break;
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (at_node) {
-                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; }
+                if (COUNT) { ts->nodes++; ts->count_top(r.cur); if (first_active_lane()) ts->node_iters++; }
                 node_step<LAYOUT>(sc, r, st);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }
@@ -250,14 +292,14 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 #define IRIS_REFILL_MIN 48
 #endif
 constexpr int kRefillMin = IRIS_REFILL_MIN;
-template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire>
-__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
-                                             Retire retire) {
+template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, int LDS_NODES, class Fetch, class Prepare, class Retire>
+__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, const uint4* top, TraceStats* ts, Fetch fetch,
+                                             Prepare prepare, Retire retire) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(r, r.o, r.d);
     r.cur = kEmptyRef;
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF, LDS_NODES> st; st.lds = lds_stack; st.ovf = ovf; st.top = top; st.sp = 0;
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
     unsigned long long pend = 0;   // wave-uniform: lanes whose next ray has been requested but not activated
@@ -298,7 +340,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
             if (at_node) {
-                if (COUNT) { ts->nodes++; if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
+                if (COUNT) { ts->nodes++; ts->count_top(r.cur); if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
                 node_step<LAYOUT>(sc, r, st);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }

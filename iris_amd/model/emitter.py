@@ -34,15 +34,25 @@ class SLFEmitter(nn.Module):
         self.register_buffer("emitter_cdf", emitter_pdf.cumsum(-1).contiguous())
         self._h = None
         self._h_device = None
+        self._struct_ver = None
+        self._rad_version = None
 
     def refresh(self):
         h, self._h = self._h, None
         if h:
             L.lib().iris_emitter_destroy(h)
 
+    @staticmethod
+    def _ver(t):
+        return (t._version, t.data_ptr(), str(t.device), tuple(t.shape))
+
     def handle(self, device):
+        """Device-side tables of this emitter.  They follow the module: the tables are rebuilt when is_emitter / emitter_area /
+        emitter_vertices change (load_state_dict, in-place edits, .to()) and the radiance table is re-uploaded when `radiance`
+        does (SLFEmitterLearn's optimiser steps, model/emitter.py:268), so a cached handle never goes stale."""
         device = torch.device(device)
-        if self._h is None or self._h_device != device:
+        struct = (self._ver(self.is_emitter), self._ver(self.emitter_area), self._ver(self.emitter_vertices))
+        if self._h is None or self._h_device != device or self._struct_ver != struct:
             self.refresh()
             ie = np.ascontiguousarray(self.is_emitter.detach().cpu().numpy(), dtype=np.uint8)
             rad = L.host_f32(self.radiance).reshape(-1, 3)
@@ -55,23 +65,24 @@ class SLFEmitter(nn.Module):
                                                 area.ctypes.data_as(C.c_void_p), area.shape[0],
                                                 verts.ctypes.data_as(C.c_void_p) if has_v else None, cdf.ctypes.data_as(C.c_void_p) if has_v else None,
                                                 device.index or 0, C.byref(h)))
-            self._h, self._h_device = h, device
+            self._h, self._h_device, self._struct_ver = h, device, struct
+            self._rad_version = self._ver(self.radiance)
+        elif self._rad_version != self._ver(self.radiance):
+            rr = self.radiance_on(device)
+            with torch.cuda.device(device):
+                L.check(L.lib().iris_emitter_set_radiance(self._h, L.ptr(rr), rr.shape[0], L.stream()))
+            self._rad_version = self._ver(self.radiance)
         return self._h
+
+    def radiance_on(self, device):
+        """`radiance` as a detached, contiguous float32 tensor on `device` (the files are loaded with map_location='cpu')."""
+        return self.radiance.detach().to(device=device, dtype=torch.float32).contiguous()
 
     def __del__(self):
         try:
             self.refresh()
         except Exception:
             pass
-
-    def _sync_radiance(self, device):
-        """SLFEmitterLearn: the device-side radiance table follows the parameter (model/emitter.py:268)."""
-        r = self.radiance
-        ver = (r._version, r.data_ptr())
-        if isinstance(r, nn.Parameter) and getattr(self, "_rad_version", None) != ver and self._h is not None:
-            rr = r.detach().to(device=device, dtype=torch.float32).contiguous()
-            L.check(L.lib().iris_emitter_set_radiance(self._h, L.ptr(rr), rr.shape[0], L.stream()))
-            self._rad_version = ver
 
     def forward(self, position):
         """surface light field from queried location (model/emitter.py:175-178)"""
@@ -90,7 +101,6 @@ class SLFEmitter(nn.Module):
         pdf = torch.empty(B, 1, device=position.device, dtype=torch.float32)
         vn = torch.empty(B, device=position.device, dtype=torch.bool)
         with torch.cuda.device(position.device):
-            self.handle(position.device); self._sync_radiance(position.device)
             L.check(L.lib().iris_eval_emitter(self.handle(position.device), self.slf.handle(position.device), L.ptr(position),
                                               L.ptr(triangle_idx), L.ptr(r), float(trace_roughness), B, L.ptr(Le), L.ptr(pdf), L.ptr(vn), L.stream()))
         return Le, pdf, vn

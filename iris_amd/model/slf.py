@@ -25,6 +25,7 @@ class VoxelSLF(nn.Module):
         self.register_buffer("count", torch.zeros(len(ii), dtype=torch.long))
         self._h = None
         self._h_device = None
+        self._ver = None
 
     # -- device handle ---------------------------------------------------------------------------------
     def refresh(self):
@@ -34,9 +35,13 @@ class VoxelSLF(nn.Module):
             L.lib().iris_slf_destroy(h)
 
     def handle(self, device):
+        """Device-side tables (int32 index grid + padded radiance rows).  Rebuilt whenever `inds` / `radiance` changed since the
+        upload (load_state_dict through a parent module, in-place edits, scatter_add), so a cached handle never goes stale."""
         device = torch.device(device)
-        if self._h is None or self._h_device != device:
+        ver = tuple((t._version, t.data_ptr(), str(t.device), tuple(t.shape)) for t in (self.inds, self.radiance))
+        if self._h is None or self._h_device != device or self._ver != ver:
             self.refresh()
+            self._ver = ver
             inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
             rad = L.host_f32(self.radiance).reshape(-1, 3)
             h = C.c_void_p()
@@ -58,9 +63,6 @@ class VoxelSLF(nn.Module):
 
     # -- reference API ---------------------------------------------------------------------------------
     def _lookup(self, x, want_idx, want_rgb):
-        if getattr(self, "_stale_radiance", False):     # scatter_add changed the buffers since the tables were uploaded
-            self._stale_radiance = False
-            self.refresh()
         x = L.require_gpu(x, torch.float32, "x").reshape(-1, 3)
         B = x.shape[0]
         idx = torch.empty(B, device=x.device, dtype=torch.int64) if want_idx else None
@@ -87,4 +89,5 @@ class VoxelSLF(nn.Module):
         cnt = L.require_gpu(self.count, torch.int64, "VoxelSLF.count buffer")
         with torch.cuda.device(x.device):
             L.check(L.lib().iris_slf_scatter_add(self.handle(x.device), L.ptr(x), L.ptr(radiance), x.shape[0], L.ptr(acc), L.ptr(cnt), L.stream()))
-        self._stale_radiance = True           # the handle's radiance copy is refreshed lazily by refresh()
+        # the kernel wrote the buffers behind torch's back: bump their version counters so that handle() re-uploads them
+        self.radiance.add_(0); self.count.add_(0)

@@ -25,8 +25,12 @@ class Scene:
         f = np.ascontiguousarray(f, dtype=np.int32).reshape(-1, 3)
         self.n_vertices, self.n_triangles = int(v.shape[0]), int(f.shape[0])
         h = C.c_void_p()
-        L.check(L.lib().iris_scene_create(v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0],
-                                          self.device.index or 0, int(layout), C.byref(h)))
+        if int(layout) == L.BVH_DEFAULT:
+            L.check(L.lib().iris_scene_create(v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0],
+                                              self.device.index or 0, C.byref(h)))
+        else:   # explicit node layout: diagnostics entry point (A/B baseline)
+            L.check(L.lib().iris_debug_scene_create(v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0],
+                                                    self.device.index or 0, int(layout), C.byref(h)))
         self._h = h
 
     @property
@@ -167,25 +171,25 @@ class _PtAccumulate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp):
-        rad = radiance.detach().to(torch.float32).contiguous()
+        rad = radiance.detach().to(device=e0.device, dtype=torch.float32).contiguous()   # emitter files are loaded on the CPU
         Lout = torch.empty(B, 3, device=rad.device, dtype=torch.float32)
         with torch.cuda.device(rad.device):
             L.check(L.lib().iris_pt_accumulate_fwd(L.ptr(rad), L.ptr(e0), L.ptr(path_of), L.ptr(e1), L.ptr(coef1), L.ptr(e2), L.ptr(coef2), L.ptr(const2),
                                                    B, spp, L.ptr(Lout), L.stream()))
         ctx.save_for_backward(e0, path_of, e1, coef1, e2, coef2)
-        ctx.meta = (B, spp, tuple(radiance.shape))
+        ctx.meta = (B, spp, tuple(radiance.shape), radiance.device)
         return Lout
 
     @staticmethod
     def backward(ctx, gL):
         e0, path_of, e1, coef1, e2, coef2 = ctx.saved_tensors
-        B, spp, shape = ctx.meta
+        B, spp, shape, rad_dev = ctx.meta
         g = torch.zeros(shape, device=gL.device, dtype=torch.float32)
-        gL = gL.contiguous().to(torch.float32)
+        gL = L.require_gpu(gL.contiguous().to(torch.float32), torch.float32, "grad of L")
         with torch.cuda.device(gL.device):
             L.check(L.lib().iris_pt_accumulate_bwd(L.ptr(gL), L.ptr(e0), L.ptr(path_of), L.ptr(e1), L.ptr(coef1), L.ptr(e2), L.ptr(coef2), B, spp,
                                                    L.ptr(g), L.stream()))
-        return (g,) + (None,) * 9
+        return (g.to(rad_dev),) + (None,) * 9
 
 
 def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, uniforms=None):
@@ -217,7 +221,8 @@ def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du,
         radiance = emitter_net.radiance
 
         if not bool(valid_next.any()):          # the reference returns the un-reduced (B*spp,3) tensor here (:347-348)
-            ext = torch.cat([radiance, radiance.new_zeros(1, 3)])
+            rdev = radiance.to(device=dev)
+            ext = torch.cat([rdev, rdev.new_zeros(1, 3)])
             return ext[torch.where(e0 >= 0, e0.long(), torch.full_like(e0, radiance.shape[0]).long())]
 
         sel = torch.nonzero(valid_next, as_tuple=False).reshape(-1)
@@ -295,7 +300,7 @@ def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir
     Lacc = torch.zeros(B, 3, device=dev)
     rows = torch.arange(B, device=dev, dtype=torch.int32)
     throughput = torch.ones(B, 3, device=dev)
-    radiance = emitter_net.radiance.detach().to(torch.float32).contiguous()
+    radiance = emitter_net.radiance_on(dev)
     mat = None
     with torch.cuda.device(dev):
         eh, sh = emitter_net.handle(dev), emitter_net.slf.handle(dev)

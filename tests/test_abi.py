@@ -10,8 +10,8 @@ import torch
 from conftest import REPO
 
 
-def _header_symbols():
-    src = open(os.path.join(REPO, "include", "iris_hip.h")).read()
+def _header_symbols(name="iris_hip.h"):
+    src = open(os.path.join(REPO, "include", name)).read()
     return sorted(set(re.findall(r"IRIS_API[^;(]*?\b(iris_\w+)\s*\(", src)))
 
 
@@ -27,12 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert os.path.exists(L.LIB_PATH), "libiris_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')"
     out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
     exported = set(re.findall(r" T (iris_\w+)", out))
-    declared = set(_header_symbols())
+    public, debug = set(_header_symbols()), set(_header_symbols("iris_hip_debug.h"))
+    assert all(n.startswith("iris_debug_") for n in debug) and not any(n.startswith("iris_debug_") for n in public)
+    declared = public | debug                                  # the drop-in boundary + the diagnostics entry points
     assert declared <= exported, declared - exported
     assert exported == declared, exported ^ declared          # nothing undeclared leaks out either
     assert set(L.PROTOTYPES) == declared
     lib = L.lib()                                              # dlopen + prototype binding
     assert lib.iris_version().startswith(b"iris_hip")
+
+
+def test_public_boundary_has_no_experiment_knobs():
+    """include/iris_hip.h is the drop-in boundary: no kernel-variant / instrumentation arguments, and the library reads no
+    environment variables (tuning goes through iris_debug_set of the diagnostics header)."""
+    src = open(os.path.join(REPO, "include", "iris_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for word in ("variant", "stats", "IRIS_BAKE_"):
+        assert word not in code, word
+    for f in os.listdir(os.path.join(REPO, "iris_amd", "csrc")):
+        assert "getenv" not in open(os.path.join(REPO, "iris_amd", "csrc", f)).read(), f
 
 
 def test_no_cpu_fallback():

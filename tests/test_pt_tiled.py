@@ -1,5 +1,5 @@
 """The large-batch variants of the path-tracing stages (pt_tiled_kernel: direction-sorted tiles + persistent-lane traversal) must give
-the bits of the one-ray-per-thread kernels; IRIS_PT_TILE_MIN forces either path.  Also re-runs the refine / path_tracing_single parity
+the bits of the one-ray-per-thread kernels; iris_debug_set("pt_tile_min") forces either path.  Also re-runs the refine / path_tracing_single parity
 tests with the tile path forced."""
 import os
 
@@ -12,13 +12,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def force_tiles():
-    old = os.environ.get("IRIS_PT_TILE_MIN")
-    os.environ["IRIS_PT_TILE_MIN"] = "1"
+    from iris_amd import _lib as L
+    L.debug_set("pt_tile_min", 1)
     yield
-    if old is None:
-        del os.environ["IRIS_PT_TILE_MIN"]
-    else:
-        os.environ["IRIS_PT_TILE_MIN"] = old
+    L.debug_set("pt_tile_min", -1)
 
 
 def _stage_outputs(scene, em, dev, N, seed):
@@ -46,13 +43,14 @@ def test_tiled_stages_equal_plain_kernels(tmp_path, N):
     from test_pt_single import _gpu_setup
     dev = torch.device("cuda:0")
     _, _, sc, em = _gpu_setup(tmp_path, dev)
-    os.environ["IRIS_PT_TILE_MIN"] = str(1 << 40)
+    from iris_amd import _lib as L
+    L.debug_set("pt_tile_min", 1 << 40)
     try:
         plain = _stage_outputs(sc, em, dev, N, seed=N)
-        os.environ["IRIS_PT_TILE_MIN"] = "1"
+        L.debug_set("pt_tile_min", 1)
         tiled = _stage_outputs(sc, em, dev, N, seed=N)
     finally:
-        del os.environ["IRIS_PT_TILE_MIN"]
+        L.debug_set("pt_tile_min", -1)
     assert len(plain) == len(tiled) == 20
     for k, (a, b) in enumerate(zip(plain, tiled)):
         assert torch.equal(a, b), k

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import REPO, golden
+from conftest import REPO, free_port, golden
 
 
 def test_stripes_partition_image():
@@ -53,7 +53,7 @@ def test_two_rank_bake_equals_single_process(oracle_mod):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1000)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import REPO, golden
+from conftest import REPO, free_port, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -66,7 +66,7 @@ def test_two_rank_gpu_bake_equals_single_process(tmp_path):
     os.makedirs(tmp_path / "ref")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
     for p in procs:
         p.start()
