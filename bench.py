@@ -6,17 +6,17 @@ primary pass + diffuse lobe + 6 specular roughness levels, every lobe at SPP=128
 from the in-kernel Philox stream, plus (N>1) the single all_gather of the 13 maps.  One ray = one (pixel, sample, lobe)
 secondary ray traced AND shaded.  N>1 shards the pixels of the SAME view over the ranks (strong scaling).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts one worker process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused specular bake kernel): achieved =
-algorithmic bytes per launch (bytes/ray from traversal counters of an instrumented launch of the same kernel on a
-pixel sample) / mean launch time measured with HIP events on the launch stream.  `cpu_baseline` is the
-CPU oracle (a port of the same algorithm, oracle/) timed on a bounded pixel sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` prices the timed kernel (bake_view_kernel: all lobes of a view behind one launch) against three
+calibrated roofs -- VALU issue, the vector-memory (L1 / TA) path, HBM-side bytes -- and names the binding one.
+`cpu_baseline` is the CPU oracle (a port of the same algorithm, oracle/) timed on a bounded pixel sample of the same workload.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,6 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD, N_CU = 1024, 256
 
 
 def build_workload(args, dev):
@@ -52,6 +53,52 @@ def build_workload(args, dev):
     return room, slf, emi, scene, emitter
 
 
+def spawn_workers(n):
+    """`python bench.py --gpus N` as a plain command: start one fresh worker process per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in its environment, the same argv) BEFORE this process makes any GPU call -- a process that has initialised the GPU is
+    never re-executed -- and exit with the worst worker's code.  Rank 0's JSON line goes to this process's stdout."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    while procs:
+        for p in list(procs):
+            c = p.poll()
+            if c is None:
+                continue
+            procs.remove(p)
+            if c != 0:
+                rc = rc or c
+                for q in procs:          # a worker failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.2)
+    sys.exit(rc)
+
+
+def load_pmc(rays_per_launch, node_bytes):
+    """Per-launch counters of the timed kernel from the committed rocprofv3 passes (profiles/pmc_r2.json; PMC counters cannot be read from
+    inside this process).  Refused -- reported as stale -- unless they were taken on exactly the kernel sources this library was built
+    from and on the same launch size."""
+    from iris_amd import _lib as L
+    path = os.path.join(REPO, "profiles", "pmc_r2.json")
+    try:
+        pj = json.load(open(path))
+    except Exception as e:     # noqa
+        return None, f"profiles/pmc_r2.json unreadable ({e})"
+    have = L.source_hash()
+    if pj.get("source_hash") != have:
+        return None, f"stale: profile taken on kernel sources {pj.get('source_hash')}, this build is {have}"
+    if abs(pj.get("rays_per_launch", 0) - rays_per_launch) > 0.01 * rays_per_launch or node_bytes != 64:
+        return None, f"profile is for {pj.get('rays_per_launch')} rays per launch, this run launches {rays_per_launch:.0f}"
+    return pj, "committed"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,24 +117,32 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pixel-block", type=int, default=8, help="order valid pixels in BxB image blocks (0 = row-major)")
     ap.add_argument("--per-lobe", action="store_true", help="one launch per lobe (spread over --streams) instead of the single-launch view kernel")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over (--per-lobe)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: bake only the stripes rank 0 of an N-GPU run would own (no collective), to "
                     "measure the per-rank time of a strong-scaling run on one GPU; the printed value is then NOT the headline metric")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="iris_debug_set tuning option (experiments), e.g. bvh_max_leaf=2")
     ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_workers(args.gpus)                     # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
     # one process per GPU.  (IRIS_BENCH_BACKEND=gloo lets a box with fewer GPUs than ranks exercise the N>1 control flow by
     # sharing devices; it is a functional check only, never a measurement.)
     backend = os.environ.get("IRIS_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    n_dev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > n_dev:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but only {n_dev} HIP device(s) are visible (RCCL needs one GPU per rank)", file=sys.stderr)
+        sys.exit(2)
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
@@ -97,11 +152,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from iris_amd import _lib as L
     from iris_amd import bake_shading as bs
     from iris_amd import sharding as sh
     from iris_amd.utils.dataset import real_ldr
     from tools import synth
 
+    for kv in args.debug_set:
+        L.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
     lobes = sorted(int(x) for x in args.lobes.split(","))
     H, W, spp = args.height, args.width, args.spp
     room, slf_np, emi_np, scene, emitter = build_workload(args, dev)
@@ -112,52 +170,55 @@ def main():
         pix_local = sh.local_pixel_ids(H, W, args.emulate_world, 0, device=dev)
     rough = bs.roughness_levels().tolist()
     n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
+    one_launch = args.variant == 0 and not args.per_lobe
 
-    ev_pairs = []   # (start,end) HIP events around every specular bake launch, on the launch stream
-    ev_diffuse = [] # the same around the diffuse-lobe launches
+    ev_view = []     # (start, end, rays) HIP events around every bake_view_kernel launch of the timed region, on the launch stream
+    ev_gather = []   # the same around the all_gather + permutation (N > 1)
 
-    def step(record_events=False, gather=True, view=0):
-        """One view: rays -> primary hits (this rank's stripes) -> 7 fused lobe kernels -> scatter -> one all_gather."""
+    def step(view=0, timed=False):
+        """One view: rays -> primary hits (this rank's stripes) -> all lobes (one launch) -> scatter -> one all_gather."""
         c2w = synth.camera(H, W, view % args.views, n_views=args.views)[1]      # the train-view sequence: cameras on a circle (cfg 3)
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         xs, ds = xs[pix_local], ds[pix_local]
         g = bs.primary_hits(scene, xs, ds, pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
         P = g["position"].shape[0]
         maps = torch.zeros(n_maps, pix_local.numel(), 3, device=dev)
-        rays = 0
-        pending = []
-        if not record_events and args.variant == 0 and not args.per_lobe:
+        rays = P * spp * len(lobes)
+        if one_launch:
             # default: the whole view behind ONE persistent launch / one tile queue (iris_bake_view)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()          # torch's current stream == the stream the kernel is launched on (L.stream())
             res = bs.bake_lobes(scene, emitter, g["position"], g["normal"], g["wo"], [None if l == 0 else rough[l - 1] for l in lobes], [spp] * len(lobes),
                                 seed=0, stream_ids=lobes, pix_id=g["pix_id"])
+            if timed:
+                e1.record(); ev_view.append((e0, e1, rays))
             pending = list(zip(lobes, res))
-            rays += P * spp * len(lobes)
-        ls = bs.LobeStreams(dev, 1 if record_events else args.streams)     # the timing pass serialises the launches
-        for l in ([] if pending else lobes):
-            if l == 0:
-                if record_events:
-                    d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    d0.record()
-                pending.append((l, ls.run(lambda: bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant))))
-                if record_events:
-                    d1.record(); ev_diffuse.append((d0, d1, P * spp))
-            else:
-                if record_events:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()      # torch's current stream == the stream the kernel is launched on (L.stream())
-                pending.append((l, ls.run(lambda l=l: bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l,
-                                                                        pix_id=g["pix_id"], variant=args.variant))))
-                if record_events:
-                    e1.record(); ev_pairs.append((e0, e1, P * spp))
-            rays += P * spp
-        ls.join()
+        else:
+            ls = bs.LobeStreams(dev, args.streams)
+            pending = []
+            for l in lobes:
+                if l == 0:
+                    pending.append((l, ls.run(lambda: bs.bake_diffuse(scene, emitter, g["position"], g["normal"], spp, seed=0, stream_id=0, pix_id=g["pix_id"], variant=args.variant))))
+                else:
+                    pending.append((l, ls.run(lambda l=l: bs.bake_specular(scene, emitter, g["position"], g["normal"], g["wo"], rough[l - 1], spp, seed=0, stream_id=l,
+                                                                            pix_id=g["pix_id"], variant=args.variant))))
+            ls.join()
         m = 0
         for l, res in pending:
             if l == 0:
                 maps[m, g["sel"]] = res; m += 1
             else:
                 maps[m, g["sel"]] = res[0]; maps[m + 1, g["sel"]] = res[1]; m += 2
-        full = maps if (not gather or (args.emulate_world > 1 and world == 1)) else sh.gather_maps(maps, H, W, world, rank)
+        if world > 1:
+            if timed:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+            full = sh.gather_maps(maps, H, W, world, rank)
+            if timed:
+                g1.record(); ev_gather.append((g0, g1))
+        else:
+            full = maps
         return rays, full
 
     def sync():
@@ -174,21 +235,23 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-view times, read after the timed region
     marks[0].record()
     for i in range(args.steps):
-        r, full = step(view=(i * args.views) // max(args.steps, 1))          # K views evenly spaced over the sequence
+        r, full = step(view=(i * args.views) // max(args.steps, 1), timed=True)      # K views evenly spaced over the sequence
         rays_local += r
         marks[i + 1].record()
     sync()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     ms_by_view = [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)]
-    if rank == 0 and not args.no_roofline and any(l > 0 for l in lobes):
-        for _ in range(2):                      # per-launch durations of the dominant kernel: separate, serialised pass (HIP events
-            step(record_events=True, gather=False)   # on the launch stream); rank 0 only, hence no collective in this pass
-        torch.cuda.synchronize()
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
     rays_t = torch.tensor([rays_local], device=dev, dtype=torch.float64)
+    ranks_seen = torch.ones(1, device=dev, dtype=torch.float64)
+    per_rank = [dt_local]
     if world > 1:
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(x.item()) for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ranks_seen, op=dist.ReduceOp.SUM)
     dt = float(t.item()); rays_total = float(rays_t.item())
     value = rays_total / dt / 1e6
 
@@ -199,64 +262,94 @@ def main():
         "config": {"workload": f"bake_shading train-view sequence ({args.steps} views evenly spaced among {args.views} cameras on a circle, one view per step), {W}x{H}, SPP={spp} per lobe, lobes={lobes} (0=diffuse,1-6=specular), synthetic room "
                                f"seed={args.scene_seed} {info['n_triangles']} triangles, SLF H={args.slf_res}, Philox uniforms",
                    "pixels_per_view": H * W, "rays_per_step": int(rays_total / max(args.steps, 1)), "ms_by_view": ms_by_view[:32], "sharding": f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 all_gather",
-                   "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"]}},
+                   "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"],
+                           "sah_cost": round(info["sah_cost"], 3), "build_seconds": round(info["build_seconds"], 2)}},
+        "multi_gpu": {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks_seen": int(ranks_seen.item()), "per_rank_ms_per_step": [round(x / max(args.steps, 1) * 1e3, 3) for x in per_rank],
+                      "gather_ms": round(float(np.mean([a.elapsed_time(b) for a, b in ev_gather])), 3) if ev_gather else None},
     }
 
-    if rank == 0 and not args.no_roofline and any(l > 0 for l in lobes) and ev_pairs:
-        # ---- roofline of the dominant kernel (bake_kernel<SPEC>) ----
-        ms = [e0.elapsed_time(e1) for e0, e1, _ in ev_pairs]
-        rays_per_launch = float(np.mean([n for _, _, n in ev_pairs]))
+    if rank == 0 and not args.no_roofline and one_launch and ev_view:
+        # ---- roofline of the timed kernel (bake_view_kernel: all lobes of a view behind one launch) ----
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in ev_view]
+        rays_per_launch = float(np.mean([n for _, _, n in ev_view]))
         avg_ms = float(np.mean(ms))
-        # algorithmic bytes/ray: instrumented launch of the same kernel on every 16th pixel, all six roughness levels
+        rate = rays_per_launch / (avg_ms * 1e-3)                       # rays / s inside the kernel
+        # (a) per-ray work, live: instrumented launches (include/iris_hip_debug.h) of the same tile code on a pixel sample of view 0, every lobe
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         g = bs.primary_hits(scene, xs[pix_local], ds[pix_local], pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
-        # every 16th block of 8192 consecutive pixels (whole tiles, so that the tile-sorted kernel sees its real coherence)
         nP = g["position"].shape[0]
         sel = torch.arange(nP, device=dev)
-        sel = sel[(sel // 8192) % 16 == 3] if nP > 16 * 8192 else sel
+        sel = sel[(sel // 8192) % 16 == 3] if nP > 16 * 8192 else sel      # every 16th block of 8192 consecutive pixels (whole tiles: real coherence)
         stats = torch.zeros(16, device=dev, dtype=torch.int64)
-        for l in range(1, 7):
-            bs.bake_specular(scene, emitter, g["position"][sel], g["normal"][sel], g["wo"][sel], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"][sel], stats=stats, variant=args.variant)
+        for l in lobes:
+            if l == 0:
+                bs.bake_diffuse(scene, emitter, g["position"][sel], g["normal"][sel], spp, seed=0, stream_id=0, pix_id=g["pix_id"][sel], stats=stats)
+            else:
+                bs.bake_specular(scene, emitter, g["position"][sel], g["normal"][sel], g["wo"][sel], rough[l - 1], spp, seed=0, stream_id=l, pix_id=g["pix_id"][sel], stats=stats)
         torch.cuda.synchronize()
         st = stats.cpu().numpy().astype(np.float64)
         n_node, n_tri = st[1] / st[0], st[2] / st[0]
-        # fixed per-ray traffic: SLF index 4 B + radiance row 16 B + emitter ordinal 4 B + hit-triangle refetch 48 B
-        # per-pixel traffic amortised over spp: pos+nrm+wo 36 B + pix_id 4 B in, 24 B out
-        tri_read = 48   # of the 64-B record a triangle test reads p0 / e1 / e2 / id (3 x 16 B), the hit-point refetch p0 / p1 / p2 (3 x 16 B)
-        bytes_per_ray = n_node * info["node_bytes"] + n_tri * tri_read + (4 + 16 + 4 + tri_read) + (36 + 4 + 24) / spp
-        achieved = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
-        # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 --pmc result
-        # for the same kernel / workload is reported when the configuration matches (see profiles/traffic_r1.json)
-        traffic = None
-        pmc = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "traffic_r1.json")))
-            if args.variant in (0, 2) and abs(tj["rays_per_launch"] - rays_per_launch) < 0.01 * rays_per_launch and info["node_bytes"] == 64:
-                traffic = float(tj["traffic_bytes"])
-                pmc = tj.get("pmc")
-        except Exception:
-            traffic = None
-        result["roofline"] = {"bound": "hbm", "kernel": "bake_kernel<SPEC=true>" if args.variant == 1 else "bake_tile_kernel<SPEC=true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "pmc": pmc,
-                              # the bound that actually binds: VALU issue.  wave-instructions per ray from the committed PMC run x the live kernel rate,
-                              # against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-                              "valu_issue": ({"achieved_Gwinst_per_s": round(pmc["wave_instructions_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / 1e9, 1),
-                                              "peak_Gwinst_per_s": round(1024 * 2.4e9 / 4 / 1e9, 1),
-                                              "frac": round(pmc["wave_instructions_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / (1024 * 2.4e9 / 4), 3),
-                                              "simd_lane_utilisation": pmc.get("simd_lane_utilisation")} if pmc else None),
-                              "diffuse_lobe_only": ({"launch_ms": round(float(np.mean([a.elapsed_time(b) for a, b, _ in ev_diffuse])), 3),
-                                                     "mrays_per_s": round(float(np.mean([n for _, _, n in ev_diffuse])) / float(np.mean([a.elapsed_time(b) for a, b, _ in ev_diffuse])) / 1e3, 1)}
-                                                    if ev_diffuse else None),
-                              "note": "algorithmic bytes are served by L1/L2/Infinity Cache (working set ~160 MB), so achieved/HBM-peak is not a utilisation figure; "
-                                      "the kernel is VALU-issue bound (DESIGN.md section 5); the timed region runs all lobes in one bake_view_kernel launch, launch_ms / achieved are priced on the per-lobe specular "
-                                      "kernel (same tile code) in a separate serialised pass and agree with profiles/r1_final_kernel_stats.csv",
-                              "traffic_note": "bytes per launch (r=1.0 lobe), rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, profiles/traffic_r1.json" if traffic else None,
-                              "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
-                              "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3),
-                              "drain": {"frac_of_node_iterations": round(st[10] / max(st[3], 1), 4), "lane_util": round(st[9] / max(st[10] * 64, 1), 3)}, "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
-                              "stack_depth_frac_gt_8_12_16": [round(st[5] / st[0], 4), round(st[6] / st[0], 4), round(st[7] / st[0], 5)],
-                              "launch_ms": round(avg_ms, 3), "launch_ms_by_roughness_level": [round(float(np.mean(ms[i::len([l for l in lobes if l > 0])])), 2) for i in range(len([l for l in lobes if l > 0]))],
-                              "launches": len(ms), "mrays_per_s_kernel": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1)}
+        # SURVEY.md section 8(d)'s algorithmic bytes: nodes x 64 B + triangle tests x 48 B + SLF index 4 + radiance row 16 + emitter ordinal 4 + hit-triangle
+        # re-read 48, + per-pixel records amortised over spp.  Served by L1 / L2 / Infinity Cache, NOT by HBM: reported, not used as a roof.
+        bytes_per_ray = n_node * info["node_bytes"] + n_tri * 48 + (4 + 16 + 4 + 48) + (36 + 4 + 24) / spp
+        work = {"nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2), "simd_lane_util_nodes": round(st[1] / max(st[3] * 64, 1), 3),
+                "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
+                "drain": {"frac_of_node_iterations": round(st[10] / max(st[3], 1), 4), "lane_util": round(st[9] / max(st[10] * 64, 1), 3)},
+                "stack_depth_frac_gt_8_12_16": [round(st[5] / st[0], 4), round(st[6] / st[0], 5), round(st[7] / st[0], 6)],
+                "top_of_tree_visits_per_ray_lt_21_85_341_1365_nodes": [round(st[k] / st[0], 2) for k in (11, 12, 13, 14)]}
+        assert 0 <= st[7] <= st[6] <= st[5] <= st[0] and st[3] * 64 >= st[1], "instrumented counters violate their invariants"
+        # (b) counters of the same kernel from the committed rocprofv3 passes, refused when stale
+        pj, src = load_pmc(rays_per_launch, info["node_bytes"])
+        roofs, traffic, bound = None, None, None
+        if pj:
+            c, pr = pj["counters"], pj["rays_per_launch"]
+            clock = c["GRBM_GUI_ACTIVE"] / 8 / (pj["duration"]["avg_ns"] * 1e-9)          # shader clock the kernel held in the profiled run (Hz)
+            cal = pj["calibration"]
+            # VALU issue.  gfx950 issues `fast` VALU instructions (v_fma_f32, v_mul/add/sub_f32, v_add_u32, v_and/or_b32, v_mov_b32, v_lshrrev_b32) at 2 cycles
+            # per wave64 and pairs them with other work; every other VALU instruction (v_fma_mix, v_perm, v_cndmask, v_cmp, v_min/max, v_cvt ...) holds
+            # the SIMD's issue for 4 cycles, transcendentals for 8 (tools/microbench valu: 905 vs 520-590 vs 295 G wave-inst/s chip-wide).  The roof of an
+            # instruction stream whose complex share is >= 1/2 is therefore complex_instructions x 4 cycles <= SIMD cycles.
+            cf = cal["complex_frac"]
+            valu_inst_per_ray = c["SQ_INSTS_VALU"] / pr
+            valu_ach = valu_inst_per_ray * cf * rate / 1e9                       # G complex-issue slots / s
+            valu_peak = N_SIMD * clock / 4 / 1e9
+            # vector-memory path (TA / L1): a wave64 load that touches n distinct 64-B lines costs the CU's TA max(9.9, 3.5 + 0.39 n) cycles when it hits L1
+            # (tools/microbench gather: 28.1 cycles at 64 lines, 16.1 at 32, 9.9 at <= 16); lines per load = TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD,
+            # L1 misses priced at the L2 / Infinity-Cache line rates of the same benchmark.
+            loads_per_ray = (c["SQ_INSTS_VMEM_RD"] + c.get("SQ_INSTS_VMEM_WR", 0.0)) / pr
+            lines_per_load = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / max(c["SQ_INSTS_VMEM_RD"], 1)
+            l1_miss = c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1)
+            l2_miss = c["TCC_MISS_sum"] / max(c["TCC_REQ_sum"], 1)
+            cyc_line = (1 - l1_miss) * cal["ta_cycles_per_line_l1"] + l1_miss * ((1 - l2_miss) * cal["ta_cycles_per_line_l2"] + l2_miss * cal["ta_cycles_per_line_mall"])
+            cyc_load = max(cal["ta_cycles_min_per_load"], cal["ta_cycles_base_per_load"] + cyc_line * lines_per_load)
+            ta_ach = loads_per_ray * cyc_load * rate / 1e9                       # G TA cycles / s
+            ta_peak = N_CU * clock / 1e9
+            # HBM side: bytes that left the L2s (FETCH_SIZE + WRITE_SIZE, KB), against the 8 TB/s HBM peak
+            traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            hbm_ach = traffic / pr * rate / 1e9
+            roofs = {
+                "valu": {"achieved": round(valu_ach, 1), "peak": round(valu_peak, 1), "unit": "G complex-issue slots/s", "frac": round(valu_ach / valu_peak, 4),
+                         "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "complex_issue_share": cf, "profiled_clock_GHz": round(clock / 1e9, 3),
+                         "simd_lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"] * 64, 1), 3)},
+                "l1_ta": {"achieved": round(ta_ach, 1), "peak": round(ta_peak, 1), "unit": "G TA cycles/s", "frac": round(ta_ach / ta_peak, 4),
+                          "wave_loads_per_ray": round(loads_per_ray, 2), "lines_per_wave_load": round(lines_per_load, 1), "ta_cycles_per_wave_load": round(cyc_load, 1),
+                          "l1_hit": round(1 - l1_miss, 3), "l2_hit": round(1 - l2_miss, 3), "ta_busy_counter": round(c["TA_TA_BUSY_sum"] / N_CU / (c["GRBM_GUI_ACTIVE"] / 8), 3),
+                          "td_busy_counter": round(c["TD_TD_BUSY_sum"] / N_CU / (c["GRBM_GUI_ACTIVE"] / 8), 3)},
+                "hbm": {"achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
+                        "bytes_per_ray": round(traffic / pr, 1), "note": "raw FETCH_SIZE + WRITE_SIZE (random 64-B line fetches; the guide's x2 correction is calibrated on wide streams and is not applied)"},
+            }
+            bound = max(roofs, key=lambda k: roofs[k]["frac"])
+        rl = {"kernel": "bake_view_kernel<Q8> (all lobes of a view, one persistent launch)", "launch_ms": round(avg_ms, 3), "launches": len(ms),
+              "rays_per_launch": int(rays_per_launch), "mrays_per_s_kernel": round(rate / 1e6, 1), "pmc_source": src,
+              "pmc_file": "profiles/pmc_r2.json" if pj else None, "roofs": roofs, "traffic": traffic,
+              "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "algorithmic_GBps": round(bytes_per_ray * rate / 1e9, 1),
+              "algorithmic_note": "SURVEY 8(d) byte model; these bytes are served by L1 / L2 / Infinity Cache, so the figure exceeds the HBM peak and is not a roof",
+              "work_per_ray": work}
+        if roofs:
+            rl.update({"bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"], "unit": roofs[bound]["unit"], "frac": roofs[bound]["frac"]})
+        else:
+            rl.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
+        result["roofline"] = rl
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----
@@ -280,27 +373,31 @@ def main():
                     oracle.bake(osc, oem, pos[sel], nrm[sel], spp, wo=wo[sel], roughness=rough[l - 1], seed=0, stream=l, pix_id=sel.astype(np.int32))
                 n += n_px * spp
             return n, time.perf_counter() - t0
-        # thread count: the host may expose more hardware threads than this job can use (cgroup quota / SMT): take the
-        # fastest of {all, 1/2, 1/4, 1/8} on a short calibration sample and report THAT as `cores`
+        # thread count: the host may expose more hardware threads than this job can use (cgroup quota / SMT): every candidate of
+        # {all, 1/2, 1/4, 1/8} is calibrated on a short sample and reported; the headline sample runs with the fastest
         ncpu = os.cpu_count() or 1
-        best = (0.0, 1)
+        calib = {}
         for th in sorted({max(1, ncpu // d) for d in (1, 2, 4, 8)}):
             oracle.set_num_threads(th)
-            n, dtc = cpu_run(max(th * 8, 64))
-            n, dtc = cpu_run(max(th * 8, 64))
-            if n / dtc > best[0]:
-                best = (n / dtc, th)
-        rate, threads = best
+            cpu_run(max(th * 8, 64))
+            n, dtc = cpu_run(max(th * 16, 128))
+            calib[th] = round(n / dtc / 1e6, 3)
+        threads = max(calib, key=calib.get)
         oracle.set_num_threads(threads)
-        n_px = int(min(len(pos), max(threads * 8, rate * args.cpu_seconds / (spp * len(lobes)))))
+        n_px = int(min(len(pos), max(threads * 8, calib[threads] * 1e6 * args.cpu_seconds / (spp * len(lobes)))))
         n, dtc = cpu_run(n_px)
-        result["cpu_baseline"] = {"value": round(n / dtc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                                  "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, "
-                                            f"OpenMP x{threads} (fastest of 1/1,1/2,1/4,1/8 of {ncpu} hw threads)"}
+        cpu_model = "unknown"
+        try:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:     # noqa
+            pass
+        result["cpu_baseline"] = {"value": round(n / dtc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "cpu_model": cpu_model, "hw_threads": ncpu,
+                                  "calibration_mrays_per_s_by_threads": calib,
+                                  "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, OpenMP x{threads}"}
         result["gpu_over_cpu"] = round(value / (n / dtc / 1e6), 1)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

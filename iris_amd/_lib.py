@@ -97,6 +97,19 @@ def lib():
     return _lib
 
 
+def source_hash():
+    """sha256 over the kernel sources and the ABI headers: stamps profiles (tools/pmc_summary.py) so that bench.py can refuse counters
+    that were taken on other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = sorted(os.path.join("iris_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip", ".cpp")))
+    files += [os.path.join("include", "iris_hip.h"), os.path.join("include", "iris_hip_debug.h")]
+    for f in files:
+        h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def debug_set(key, value):
     """iris_debug_set (include/iris_hip_debug.h): process-wide tuning option; value < 0 restores the default."""
     check(lib().iris_debug_set(key.encode(), int(value)))

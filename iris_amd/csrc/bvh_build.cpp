@@ -1,4 +1,5 @@
-// Binned-SAH BVH2 build + collapse to a W-wide tree (host only).  See bvh_build.h.
+// Binned-SAH BVH2 build (down to single triangles) + SAH-optimal collapse to a W-wide tree by dynamic programming (host only).
+// See bvh_build.h.
 #include "bvh_build.h"
 
 #include <algorithm>
@@ -34,6 +35,7 @@ struct Node2 {
     Box b;
     int32_t left = -1, right = -1;  // internal
     int32_t start = 0, count = 0;   // leaf if count > 0
+    int32_t first = 0, ntri = 0;    // the subtree's triangles: order[first, first + ntri)
 };
 
 struct Builder {
@@ -51,7 +53,7 @@ struct Builder {
             const TriInfo& t = tri[order[i]];
             b.grow(t.b); cb.grow(t.c, t.c);
         }
-        nd.b = b; nd.left = nd.right = -1; nd.start = start; nd.count = count;
+        nd.b = b; nd.left = nd.right = -1; nd.start = start; nd.count = count; nd.first = start; nd.ntri = count;
         if (count == 1) return me;
 
         int best_axis = -1, best_bin = -1;
@@ -78,8 +80,9 @@ struct Builder {
                 if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
             }
         }
-        // SAH termination for small nodes: leaf cost = count * A ; split cost = A (one traversal step) + children
-        if (count <= max_leaf) {
+        // SAH termination for small nodes: leaf cost = count * A ; split cost = A (one traversal step) + children.
+        // (max_leaf <= 0: split down to single triangles; the wide collapse decides where the leaves are)
+        if (max_leaf > 0 && count <= max_leaf) {
             float a = b.area();
             if (best_axis < 0 || (float)count * a <= 1.0f * a + best_cost) return me;
         }
@@ -123,8 +126,9 @@ float sah_of(const Node2* nodes, int32_t i, float root_area) {
 
 }  // namespace
 
-WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces, int64_t nf, int width, int max_leaf,
-                       float pad_rel) {
+WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces, int64_t nf, int width, int leaf_tris,
+                       float pad_rel, float tri_cost) {
+    leaf_tris = std::min(7, std::max(1, leaf_tris));
     WideBvh out;
     out.width = width;
     for (int k = 0; k < 3; ++k) { out.root_lo[k] = 0.f; out.root_hi[k] = 0.f; }
@@ -156,54 +160,87 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
 
     std::vector<Node2> nodes((size_t)(2 * nf));
     Builder bld;
-    bld.tri = tri.data(); bld.order = order.data(); bld.nodes = nodes.data(); bld.max_leaf = max_leaf;
+    bld.tri = tri.data(); bld.order = order.data(); bld.nodes = nodes.data(); bld.max_leaf = 0;   // down to single triangles
     bld.build(0, (int32_t)nf, 0);
-    out.sah_cost = sah_of(nodes.data(), 0, std::max(nodes[0].b.area(), 1e-30f));
     for (int k = 0; k < 3; ++k) { out.root_lo[k] = nodes[0].b.lo[k] - pad; out.root_hi[k] = nodes[0].b.hi[k] + pad; }
 
-    // ---- collapse to `width`-wide nodes, breadth first; internal children of a node get consecutive indices ----
+    // ---- collapse to `width`-wide nodes: SAH-optimal for the given binary topology (dynamic programming over "a subtree represented
+    // by at most i children of one wide node", Ylitie et al. 2017, section 3.1), breadth first; the internal children of a node get
+    // consecutive indices.  cost = sum over wide nodes A * 1 + sum over leaves A * triangles * tri_cost (areas relative to the root).
+    //   C(n,1) = min(leaf(n), A_n + D(n,W));   D(n,j) = min_k C(l,k) + C(r,j-k);   C(n,i) = min(D(n,i), C(n,i-1))
+    const int W = std::min(std::max(width, 2), kMaxWidth);
+    const int32_t n2 = bld.next.load();
+    struct Dp { float c[kMaxWidth]; uint8_t k[kMaxWidth + 1]; uint8_t leaf; };   // c[i-1] = C(n,i), i = 1..W-1; k[j] = left share of D(n,j), 0 = "use C(n,j-1)"
+    std::vector<Dp> dp((size_t)n2);
+    const float root_area = std::max(nodes[0].b.area(), 1e-30f);
+    for (int32_t i = n2 - 1; i >= 0; --i) {          // children have larger indices than their parent
+        const Node2& nd = nodes[(size_t)i];
+        Dp& d = dp[(size_t)i];
+        const float a = nd.b.area() / root_area;
+        const float leaf = nd.ntri <= leaf_tris ? a * (float)nd.ntri * tri_cost : kInf;
+        for (int j = 0; j <= W; ++j) d.k[j] = 0;
+        if (nd.count > 0) { d.leaf = 1; for (int j = 0; j < W; ++j) d.c[j] = leaf; continue; }
+        const Dp &l = dp[(size_t)nd.left], &r = dp[(size_t)nd.right];
+        float dist[kMaxWidth + 1];
+        for (int j = 2; j <= W; ++j) {
+            dist[j] = kInf;
+            for (int k = 1; k < j; ++k) {
+                const float c = l.c[k - 1] + r.c[j - k - 1];
+                if (c < dist[j]) { dist[j] = c; d.k[j] = (uint8_t)k; }
+            }
+        }
+        const float internal = a + dist[W];
+        d.leaf = leaf <= internal;
+        d.c[0] = std::min(leaf, internal);
+        for (int j = 2; j < W; ++j) {
+            if (dist[j] < d.c[j - 2]) d.c[j - 1] = dist[j];
+            else { d.c[j - 1] = d.c[j - 2]; d.k[j] = 0; }
+        }
+        d.c[W - 1] = 0.f;
+    }
+    out.sah_cost = dp[0].c[0];
+
     out.tri_order.reserve((size_t)nf);
+    struct Child { int32_t n2; bool leaf; };
+    // the children a subtree contributes when it is given `slots` slots of its parent's wide node
+    auto emit = [&](auto&& self, int32_t n, int slots, std::vector<Child>& outc) -> void {
+        const Node2& nd = nodes[(size_t)n];
+        const Dp& d = dp[(size_t)n];
+        if (nd.count > 0 || slots == 1) { outc.push_back({n, nd.count > 0 || d.leaf != 0}); return; }
+        if (d.k[slots] == 0) { self(self, n, slots - 1, outc); return; }
+        self(self, nd.left, d.k[slots], outc);
+        self(self, nd.right, slots - d.k[slots], outc);
+    };
     struct Item { int32_t n2; int32_t wide; int depth; };
     std::vector<Item> queue;
     out.nodes.push_back(empty_node());
     queue.push_back({0, 0, 1});
-    // a root that is itself a leaf becomes a wide node with one leaf child
+    std::vector<Child> ch;
     for (size_t qi = 0; qi < queue.size(); ++qi) {
-        Item it = queue[qi];
+        const Item it = queue[qi];
         out.depth = std::max(out.depth, it.depth);
-        int32_t cand[kMaxWidth]; int nc = 0;
+        ch.clear();
         const Node2& r = nodes[(size_t)it.n2];
-        if (r.count > 0) { cand[nc++] = it.n2; }
-        else { cand[nc++] = r.left; cand[nc++] = r.right; }
-        while (nc < width) {
-            int pick = -1; float best = -1.f;
-            for (int i = 0; i < nc; ++i) {
-                const Node2& c = nodes[(size_t)cand[i]];
-                if (c.count == 0) { float a = c.b.area(); if (a > best) { best = a; pick = i; } }
-            }
-            if (pick < 0) break;
-            const Node2& c = nodes[(size_t)cand[pick]];
-            cand[pick] = c.left; cand[nc++] = c.right;
-        }
+        if (r.count > 0 || (it.n2 == 0 && dp[0].leaf)) ch.push_back({it.n2, true});      // a root that is itself a leaf: one leaf child
+        else { emit(emit, r.left, dp[(size_t)it.n2].k[W], ch); emit(emit, r.right, W - dp[(size_t)it.n2].k[W], ch); }
         WideNode w = empty_node();
-        w.n = nc;
-        // internal children first get consecutive wide indices
-        for (int i = 0; i < nc; ++i) {
-            const Node2& c = nodes[(size_t)cand[i]];
+        w.n = (int)ch.size();
+        for (int i = 0; i < w.n; ++i) {          // internal children first get consecutive wide indices
+            const Node2& c = nodes[(size_t)ch[(size_t)i].n2];
             for (int k = 0; k < 3; ++k) { w.lo[i][k] = c.b.lo[k] - pad; w.hi[i][k] = c.b.hi[k] + pad; }
-            if (c.count == 0) {
+            if (!ch[(size_t)i].leaf) {
                 w.child[i] = (int32_t)out.nodes.size();
                 out.nodes.push_back(empty_node());
-                queue.push_back({cand[i], w.child[i], it.depth + 1});
+                queue.push_back({ch[(size_t)i].n2, w.child[i], it.depth + 1});
             }
         }
-        for (int i = 0; i < nc; ++i) {
-            const Node2& c = nodes[(size_t)cand[i]];
-            if (c.count > 0) {
+        for (int i = 0; i < w.n; ++i) {
+            const Node2& c = nodes[(size_t)ch[(size_t)i].n2];
+            if (ch[(size_t)i].leaf) {
                 w.child[i] = -1;
                 w.leaf_start[i] = (int32_t)out.tri_order.size();
-                w.leaf_count[i] = c.count;
-                for (int32_t j = c.start; j < c.start + c.count; ++j) out.tri_order.push_back(order[(size_t)j]);
+                w.leaf_count[i] = c.ntri;
+                for (int32_t j = c.first; j < c.first + c.ntri; ++j) out.tri_order.push_back(order[(size_t)j]);
             }
         }
         out.nodes[(size_t)it.wide] = w;

@@ -40,11 +40,12 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
 
 // ---- diagnostics options (iris_hip_debug.h): process-wide, set by tests / experiments only; -1 = the built-in default
-static long long g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1;
+static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1;
 extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     if (!key) return fail(IRIS_ERR_ARG, "iris_debug_set: null key");
     const std::string k(key);
     if (k == "bvh_max_leaf") g_opt_bvh_max_leaf = value;
+    else if (k == "bvh_tri_cost_x100") g_opt_bvh_tri_cost_x100 = value;
     else if (k == "phase_min") g_opt_phase_min = value;
     else if (k == "tile_target_rays") g_opt_tile_target_rays = value;
     else if (k == "tiles_per_block") g_opt_tiles_per_block = value;
@@ -119,7 +120,8 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     auto t0 = std::chrono::steady_clock::now();
     int max_leaf = 4;
     if (g_opt_bvh_max_leaf > 0) max_leaf = (int)std::min<long long>(7, g_opt_bvh_max_leaf);   // iris_debug_set("bvh_max_leaf")
-    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf);
+    const float tri_cost = g_opt_bvh_tri_cost_x100 > 0 ? (float)g_opt_bvh_tri_cost_x100 * 0.01f : 0.7f;   // iris_debug_set("bvh_tri_cost_x100")
+    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost);
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
 
     // ---- encode nodes ----

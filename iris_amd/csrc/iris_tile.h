@@ -46,14 +46,28 @@ __device__ __forceinline__ void stage_top_nodes(const SceneDev& sc, uint4* s_top
 // workgroup share their CU's write-through L1; an agent-scope __threadfence() would flush that L1 -- including the hot upper BVH
 // levels -- once per tile and was measured 9 % slower per fence pair).  Ends with a barrier: hits are visible to the caller.
 //   s_top (LDS_NODES > 0)       : the first LDS_NODES nodes staged in LDS by stage_top_nodes()
-template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, int LDS_NODES, class PhaseA, class FetchRay, class Prepare, class Retire>
+//   tail (MERGE_TAIL)           : LDS for the merged tail: when the list is exhausted a wave that is down to <= kTailMax unfinished rays
+//                                 parks their traversal state here (best hit, current reference, stack depth; the stack contents stay
+//                                 in the parking lane's column) and leaves; after a barrier wave 0 adopts all parked rays of the tile
+//                                 (<= 4 x kTailMax = 64): each adopting lane copies the parked lane's stack column into its own and
+//                                 continues the traversal where it stopped -- one wave's tail instead of four, nothing is re-traversed.
+struct TileTail {
+    float4 hit[4 * kTailMax];      // (t, u, v, leaf slot)
+    uint32_t cur[4 * kTailMax];    // node / leaf reference the ray was at
+    int32_t id[4 * kTailMax];      // triangle id of the best hit (tie-break)
+    uint32_t meta[4 * kTailMax];   // ray id | stack depth << 16 | parking thread << 24
+    int n;
+};
+template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, int LDS_NODES, bool MERGE_TAIL, class PhaseA, class FetchRay, class Prepare, class Retire>
 __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk, uint32_t* ovf,
-                                                const uint4* s_top, TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare, Retire retire) {
+                                                const uint4* s_top, TileTail* tail, TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare,
+                                                Retire retire) {
     static_assert(TILE_STACK * kBlock * 4 >= CAP + 2 * 256 * 4, "stack region too small to alias the sort keys");
     uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
     uint32_t* s_hist = s_stack + CAP / 4;
     uint32_t* s_cur = s_hist + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (MERGE_TAIL && tid == 0) tail->n = 0;     // (published by the barriers below, long before the first wave can park)
     // ---- phase A: sample, park, histogram of the direction bins
     for (int r = tid; r < nr; r += kBlock) {
         const uint32_t key = phase_a(r);
@@ -91,9 +105,56 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
             return true;
         };
         auto ret = [&](const Hit& h) { retire(my_r, h); };
-        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF, LDS_NODES>(sc, s_stack + tid, ovf, s_top, &ts, fetch, prepare, ret);
+        auto park = [&](const RayState& r, const Stack<TILE_STACK, GLOBAL_OVF, LDS_NODES>& st) {
+            const unsigned long long m = __ballot(1);
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&tail->n, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+            tail->hit[i] = make_float4(r.h.t, r.h.u, r.h.v, __int_as_float(r.h.slot));
+            tail->cur[i] = r.cur;
+            tail->id[i] = r.h.id;
+            tail->meta[i] = (uint32_t)my_r | (uint32_t)st.sp << 16 | (uint32_t)tid << 24;
+        };
+        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF, LDS_NODES, MERGE_TAIL ? kTailMax : 0>(
+            sc, s_stack + tid, ovf, s_top, &ts, fetch, prepare, ret, [](RayState&, Stack<TILE_STACK, GLOBAL_OVF, LDS_NODES>&) {}, park);
     }
     __syncthreads();
+    if (MERGE_TAIL) {
+        // ---- merged tail: the <= 64 parked rays of the tile, adopted by wave 0
+        const int n_tail = tail->n;
+        if (n_tail > 0 && wave == 0) {
+            int my_r = 0;
+            bool first = true;
+            uint32_t meta = 0;
+            auto fetch = [&](f3& o, f3& d) -> bool {
+                if (!first || lane >= n_tail) { first = false; return false; }
+                first = false;
+                meta = tail->meta[lane];
+                my_r = (int)(meta & 0xffffu);
+                fetch_ray(my_r, o, d);
+                return true;
+            };
+            auto resume = [&](RayState& r, Stack<TILE_STACK, GLOBAL_OVF, LDS_NODES>& st) {
+                const float4 ph = tail->hit[lane];
+                r.h.t = ph.x; r.h.u = ph.y; r.h.v = ph.z; r.h.slot = __float_as_int(ph.w); r.h.id = tail->id[lane];
+                r.cur = tail->cur[lane];
+                const int sp = (int)((meta >> 16) & 0xffu), src = (int)(meta >> 24);
+                // copy the parking lane's stack column (level by level: every lane reads before any lane writes, so columns of wave 0
+                // that are both source and destination are safe)
+                for (int k = 0; k < sp; ++k) {
+                    uint32_t v;
+                    if (k < TILE_STACK) v = s_stack[k * kBlock + src];
+                    else v = ovf[(uint32_t)min(k - TILE_STACK, kStackCapacity - TILE_STACK - 1) * kBlock + src];
+                    st.push(v);
+                }
+            };
+            auto ret = [&](const Hit& h) { retire(my_r, h); };
+            trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF, LDS_NODES, 0>(sc, s_stack + tid, ovf, s_top, &ts, fetch, prepare, ret, resume,
+                                                                              [](const RayState&, const Stack<TILE_STACK, GLOBAL_OVF, LDS_NODES>&) {});
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace iris

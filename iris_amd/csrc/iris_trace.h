@@ -87,23 +87,9 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 
 // BVH4_F32 traversal: node = {lox[4],hix[4],loy[4],hiy[4],loz[4],hiz[4],ref[4],pad[4]} (128 B, one L2 line).
 // ref: internal -> node index; leaf -> 0x80000000 | start<<3 | count; unused slot -> inverted box (never hit).
 // -------------------------------------------------------------------------------------------------------
-// Selects through an explicit SGPR-pair lane mask.  Measured (tools/microbench, 7 waves/SIMD): v_cndmask_b32_e64 with an SGPR-pair mask
-// issues at the ordinary 4-cycle rate (548 G wave-inst/s chip-wide), the VOP2 form that reads VCC implicitly at 108 G/s (~20 cycles), 6-7
-// cycles when VCC was written just before.  hipcc picks VCC for about half of the selects of node_step; these helpers pin the mask form.
-typedef unsigned long long lanemask_t;
-__device__ __forceinline__ lanemask_t m_le(float a, float b) { lanemask_t m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
-__device__ __forceinline__ lanemask_t m_lt(float a, float b) { lanemask_t m; asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
-__device__ __forceinline__ float m_sel(lanemask_t m, float x, float y) { float r; asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(x), "v"(y), "s"(m)); return r; }          // m ? x : y
-__device__ __forceinline__ uint32_t m_sel(lanemask_t m, uint32_t x, uint32_t y) { uint32_t r; asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(x), "v"(y), "s"(m)); return r; }
-#ifdef IRIS_SEL_ASM
-#define IRIS_CE(ka, ra, kb, rb) { const lanemask_t sw = m_lt(kb, ka); const float tk = m_sel(sw, kb, ka); kb = m_sel(sw, ka, kb); ka = tk; \
-                                  const uint32_t tr = m_sel(sw, rb, ra); rb = m_sel(sw, ra, rb); ra = tr; }
-#define IRIS_HITKEY(tn, tf) m_sel(m_le(tn, tf), tn, INFINITY)
-#else
 #define IRIS_CE(ka, ra, kb, rb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                   uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
 #define IRIS_HITKEY(tn, tf) ((tn) <= (tf) ? (tn) : INFINITY)
-#endif
 
 // Traversal statistics (instrumented builds only): per-lane counts, reduced by the caller.
 struct TraceStats {
@@ -183,17 +169,6 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // rounded once by the FMA: the same t as before, bit for bit.
         typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
 #define IRIS_PLANES(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
-#ifdef IRIS_SLAB_CVT
-        // A/B: byte -> float conversions (v_cvt_f32_ubyteN) + plain v_fma_f32 (double-rate on gfx950) instead of v_perm + v_fma_mix.
-        // fma((float)q, rnd(2^e * idir), b): the same real number rounded once, so the same t bit for bit (2^-24 scaling is exact).
-        const float cx = ax * 5.9604644775390625e-08f, cy = ay * 5.9604644775390625e-08f, cz = az * 5.9604644775390625e-08f;
-#define IRIS_SLABQ(K, C)                                                                                                          \
-    {                                                                                                                             \
-        float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), cx, bx), fmaf(ubyte(nyq, C), cy, by)), fmaxf(fmaf(ubyte(nzq, C), cz, bz), 0.f)); \
-        float tf = fminf(fminf(fmaf(ubyte(fxq, C), cx, bx), fmaf(ubyte(fyq, C), cy, by)), fminf(fmaf(ubyte(fzq, C), cz, bz), r.h.t)); \
-        K = IRIS_HITKEY(tn, tf);                                                                                                  \
-    }
-#else
 #define IRIS_SLABQ(K, C)                                                                                                          \
     {                                                                                                                             \
         const iris_h2 hx = IRIS_PLANES(nxq, fxq, C), hy = IRIS_PLANES(nyq, fyq, C), hz = IRIS_PLANES(nzq, fzq, C);                 \
@@ -201,7 +176,6 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
         K = IRIS_HITKEY(tn, tf);                                                                                                  \
     }
-#endif
         IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
 #undef IRIS_SLABQ
 #undef IRIS_PLANES
@@ -292,9 +266,17 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 #define IRIS_REFILL_MIN 48
 #endif
 constexpr int kRefillMin = IRIS_REFILL_MIN;
-template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, int LDS_NODES, class Fetch, class Prepare, class Retire>
+//   resume(r, st)        : called right after a lane's ray has been set up (ray_begin, empty stack): may restore a traversal that was
+//                          parked half-way -- best hit so far, current node / leaf reference, stack contents
+//   park(r, st)          : TAIL_MAX > 0 only.  Once the list is exhausted and at most TAIL_MAX lanes of the wave still hold an
+//                          unfinished ray, those lanes hand their traversal state back through park() and the wave returns: the
+//                          caller finishes the parked rays of all its waves together (tile_sort_trace's merged tail) instead of
+//                          letting every wave run its last few long rays alone at a few % lane utilisation.  Per-ray results do
+//                          not change: the same node / leaf steps are executed, by another lane.
+constexpr int kTailMax = 16;
+template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, int LDS_NODES, int TAIL_MAX, class Fetch, class Prepare, class Retire, class Resume, class Park>
 __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, const uint4* top, TraceStats* ts, Fetch fetch,
-                                             Prepare prepare, Retire retire) {
+                                             Prepare prepare, Retire retire, Resume resume, Park park) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(r, r.o, r.d);
@@ -312,6 +294,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 prepare(r.o, r.d);
                 ray_begin(r, r.o, r.d);
                 st.sp = 0;
+                resume(r, st);
                 if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
             }
             pend = 0;
@@ -328,9 +311,16 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             pend = __ballot(got);
             if (pend == 0) more = false;
         }
-        if (__ballot(r.cur != kEmptyRef) == 0) {
-            if (pend == 0 && !more) break;
-            continue;
+        {
+            const int n_act = __popcll(__ballot(r.cur != kEmptyRef));
+            if (n_act == 0) {
+                if (pend == 0 && !more) break;
+                continue;
+            }
+            if (TAIL_MAX > 0 && !more && pend == 0 && n_act <= TAIL_MAX) {      // the tail: hand the unfinished rays back
+                if (r.cur != kEmptyRef) { park(r, st); live = false; }
+                break;
+            }
         }
         // ---------------- node phase
         for (;;) {

@@ -887,10 +887,23 @@ ORC_API void orc_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream, int64_
  * ========================================================================================== */
 static const float RAY_EPS = 1500.0f * 5.9604644775390625e-08f;
 
+/* src_next (P*spp, optional): per sample, the radiance-table row eval_emitter read -- -2 - emitter ordinal for an emitter triangle,
+ * the VoxelSLF row for the radiance cache, -1 for empty space or a miss.  Parity bookkeeping: a sample whose (tri_next, src_next)
+ * differs between two evaluations of the same path is a discrete "flip"; all other differences are rounding. */
+ORC_API void orc_bake_src(const orc_scene *sc, const orc_emitter *em, const orc_slf *slf,
+                          const float *pos, const float *nrm, const float *wo, int64_t P, int spp,
+                          const float *u2, uint64_t seed, uint32_t stream, const int32_t *pix_id, float rough,
+                          float *out0, float *out1, int64_t *tri_next, int64_t *src_next, int64_t *counters);
 ORC_API void orc_bake(const orc_scene *sc, const orc_emitter *em, const orc_slf *slf,
                       const float *pos, const float *nrm, const float *wo, int64_t P, int spp,
                       const float *u2, uint64_t seed, uint32_t stream, const int32_t *pix_id, float rough,
                       float *out0, float *out1, int64_t *tri_next, int64_t *counters) {
+    orc_bake_src(sc, em, slf, pos, nrm, wo, P, spp, u2, seed, stream, pix_id, rough, out0, out1, tri_next, NULL, counters);
+}
+ORC_API void orc_bake_src(const orc_scene *sc, const orc_emitter *em, const orc_slf *slf,
+                          const float *pos, const float *nrm, const float *wo, int64_t P, int spp,
+                          const float *u2, uint64_t seed, uint32_t stream, const int32_t *pix_id, float rough,
+                          float *out0, float *out1, int64_t *tri_next, int64_t *src_next, int64_t *counters) {
     int64_t tot_nodes = 0, tot_tris = 0;
     const int specular = rough >= 0.f;
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : tot_nodes, tot_tris)
@@ -920,6 +933,11 @@ ORC_API void orc_bake(const orc_scene *sc, const orc_emitter *em, const orc_slf 
             v3 pn = h.tri >= 0 ? hit_position(sc, &h) : v3_make(0, 0, 0);
             /* eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0) (bake_shading.py:121-122) */
             v3 Le = eval_emitter1(em, slf, pn, h.tri, 1, 1.0f, 0.0f, NULL, NULL);
+            if (src_next) {   /* restates eval_emitter1's table choice (model/emitter.py:196-216) */
+                int64_t src = -1;
+                if (h.tri >= 0) src = em->is_emitter[h.tri] ? -2 - em->emitter_idx[h.tri] : slf_spatial_idx(slf, pn);
+                src_next[p * spp + s] = src;
+            }
             if (g_mode == 1) {
                 const int l = s % L;
                 if (specular) {

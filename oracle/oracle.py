@@ -269,8 +269,9 @@ def philox_u2(seed, idx0, stream, n):
 
 
 def bake(scene, emitter, position, normal, spp, wo=None, roughness=None, u2=None, seed=0, stream=0, pix_id=None,
-         want_tri=False, counters=False):
-    """bake_shading.py:108-123 (roughness None -> diffuse) / :168-188 (specular)."""
+         want_tri=False, counters=False, want_src=False):
+    """bake_shading.py:108-123 (roughness None -> diffuse) / :168-188 (specular).
+    want_tri / want_src: also return the per-sample hit triangle / radiance-table row (-2 - emitter ordinal, VoxelSLF row, or -1)."""
     position = _f32(position); normal = _f32(normal); P = position.shape[0]
     specular = roughness is not None
     wo_ = _f32(wo) if specular else None
@@ -278,13 +279,16 @@ def bake(scene, emitter, position, normal, spp, wo=None, roughness=None, u2=None
     pid = None if pix_id is None else np.ascontiguousarray(pix_id, dtype=np.int32)
     out0 = np.empty((P, 3), np.float32); out1 = np.empty((P, 3), np.float32) if specular else None
     tri = np.empty(P * spp, np.int64) if want_tri else None
+    src = np.empty(P * spp, np.int64) if want_src else None
     cnt = np.zeros(2, np.int64)
-    lib().orc_bake(scene.h, emitter.h, emitter.slf.h, _p(position), _p(normal), _p(wo_), C.c_int64(P), C.c_int(spp), _p(u2_),
-                   C.c_uint64(seed), C.c_uint32(stream), _p(pid), C.c_float(np.float32(roughness) if specular else -1.0),
-                   _p(out0), _p(out1), _p(tri), _p(cnt))
+    lib().orc_bake_src(scene.h, emitter.h, emitter.slf.h, _p(position), _p(normal), _p(wo_), C.c_int64(P), C.c_int(spp), _p(u2_),
+                       C.c_uint64(seed), C.c_uint32(stream), _p(pid), C.c_float(np.float32(roughness) if specular else -1.0),
+                       _p(out0), _p(out1), _p(tri), _p(src), _p(cnt))
     res = (out0, out1) if specular else (out0,)
     if want_tri:
         res = res + (tri,)
+    if want_src:
+        res = res + (src,)
     if counters:
         res = res + (cnt,)
     return res

@@ -89,19 +89,21 @@ def test_cli_synthetic_dataset(tmp_path):
     assert img_hw == (H, W)
     xs, ds = cameras.view_rays(views[1], img_hw, dev)
     from iris_amd.utils.denoise import Denoiser
-    ref = bs.bake_view(load_scene(str(scene_dir / "scene.obj"), device=dev), SLFEmitter(ep, sp), xs, ds, 16, [8] * 6, seed=3, image_width=W,
+    ref = bs.bake_view(load_scene(str(scene_dir / "scene.obj"), device=dev), SLFEmitter(ep, sp), xs, ds, 16, [8] * 6, seed=bs.view_seed(3, 1), image_width=W,
                        denoiser=Denoiser((W, H), dev))                  # the CLI denoises by default, as the reference does (:129, :198-200)
     np.testing.assert_array_equal(exr.read_exr(files[0]), ref["diffuse"].reshape(H, W, 3).cpu().numpy())
     np.testing.assert_array_equal(exr.read_exr(files[1 + 2 * 4]), ref["specular0"][4].reshape(H, W, 3).cpu().numpy())
     np.testing.assert_array_equal(exr.read_exr(files[2 + 2 * 5]), ref["specular1"][5].reshape(H, W, 3).cpu().numpy())
     assert float(ref["diffuse"].sum()) > 0
+    # per-view Philox keys: the noise of two views of one run is independent (view 0 keeps the plain seed)
+    assert bs.view_seed(3, 0) == 3 and bs.view_seed(3, 1) != bs.view_seed(3, 2) != 3
     mt = os.path.getmtime(files[0])
     bs.main(argv)                                                        # resume: nothing is re-baked
     assert os.path.getmtime(files[0]) == mt
     # --denoise none writes the raw Monte-Carlo maps; level 0 is never denoised (:198)
     out2 = str(tmp_path / "out_raw")
     bs.main([a if a != out else out2 for a in argv] + ["--denoise", "none"])
-    raw = bs.bake_view(load_scene(str(scene_dir / "scene.obj"), device=dev), SLFEmitter(ep, sp), xs, ds, 16, [8] * 6, seed=3, image_width=W)
+    raw = bs.bake_view(load_scene(str(scene_dir / "scene.obj"), device=dev), SLFEmitter(ep, sp), xs, ds, 16, [8] * 6, seed=bs.view_seed(3, 1), image_width=W)
     f2 = bs.output_files(out2, 1)
     np.testing.assert_array_equal(exr.read_exr(f2[0]), raw["diffuse"].reshape(H, W, 3).cpu().numpy())
     np.testing.assert_array_equal(exr.read_exr(f2[1]), exr.read_exr(files[1]))

@@ -1,0 +1,139 @@
+// Host-side quality check of the wide-BVH builder (iris_amd/csrc/bvh_build.cpp): builds the tree for a mesh dumped by
+// tools/bvh_eval/dump_room.py and traces a sample of bake-like secondary rays (origins on the surface, cosine-distributed directions
+// into the room) with the traversal rule of the kernels (iris_trace.h: ordered by entry distance, children culled by the best hit),
+// counting node visits and triangle tests per ray.  Applies the 8-bit plane quantisation of the Q8 node layout (iris_hip.hip) so that
+// the counts are those of the device tree.  Numbers agree with the instrumented GPU launches (bench.py roofline.nodes_per_ray).
+//   g++ -O2 -std=c++17 -I iris_amd/csrc tools/bvh_eval/bvh_eval.cpp iris_amd/csrc/bvh_build.cpp -lpthread -o tools/bvh_eval/bvh_eval
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "bvh_build.h"
+
+using namespace iris;
+
+struct V3 { float x, y, z; };
+static V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct QNode { float lo[4][3], hi[4][3]; };   // decoded (quantised, conservative) child boxes
+
+int main(int argc, char** argv) {
+    const char* path = argc > 1 ? argv[1] : "/tmp/room.bin";
+    const int n_rays = argc > 2 ? atoi(argv[2]) : 200000;
+    const int max_leaf = argc > 3 ? atoi(argv[3]) : 4;
+    const bool quant = argc > 4 ? atoi(argv[4]) != 0 : true;
+    const float tri_cost = argc > 5 ? (float)atof(argv[5]) : 0.7f;
+    FILE* f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); return 1; }
+    int64_t nv, nf;
+    if (fread(&nv, 8, 1, f) != 1 || fread(&nf, 8, 1, f) != 1) return 1;
+    std::vector<float> verts(nv * 3);
+    std::vector<int32_t> faces(nf * 3);
+    if (fread(verts.data(), 4, nv * 3, f) != (size_t)nv * 3 || fread(faces.data(), 4, nf * 3, f) != (size_t)nf * 3) return 1;
+    fclose(f);
+    auto t0 = std::chrono::steady_clock::now();
+    WideBvh bvh = build_wide_bvh(verts.data(), nv, faces.data(), nf, 4, max_leaf, 2e-5f, tri_cost);
+    const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const size_t nn = bvh.nodes.size();
+    // Q8 decode: per node, origin = min of child lows, per axis the smallest power of two 2^e with 255 * 2^e >= extent
+    std::vector<QNode> q(nn);
+    for (size_t i = 0; i < nn; ++i) {
+        const WideNode& w = bvh.nodes[i];
+        for (int k = 0; k < 3; ++k) {
+            float org = INFINITY, hi3 = -INFINITY;
+            for (int s = 0; s < w.n; ++s) { org = std::min(org, w.lo[s][k]); hi3 = std::max(hi3, w.hi[s][k]); }
+            const double ext = (double)hi3 - (double)org;
+            int e = -126;
+            if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
+            while (std::ldexp(255.0, e) < ext) ++e;
+            const double sc = std::ldexp(1.0, e);
+            for (int s = 0; s < 4; ++s) {
+                if (s >= w.n) { q[i].lo[s][k] = INFINITY; q[i].hi[s][k] = -INFINITY; continue; }
+                int lo = (int)std::floor(((double)w.lo[s][k] - org) / sc), hi = (int)std::ceil(((double)w.hi[s][k] - org) / sc);
+                lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
+                q[i].lo[s][k] = quant ? (float)(org + lo * sc) : w.lo[s][k]; q[i].hi[s][k] = quant ? (float)(org + hi * sc) : w.hi[s][k];
+            }
+        }
+    }
+    // rays: area-weighted surface points, cosine hemisphere around the normal that faces the room centre
+    std::mt19937_64 rng(1234);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    std::vector<double> cdf(nf);
+    auto vert = [&](int64_t fi, int k) { const float* p = verts.data() + (int64_t)faces[fi * 3 + k] * 3; return V3{p[0], p[1], p[2]}; };
+    double acc = 0;
+    V3 centre{0, 0, 0};
+    for (int64_t i = 0; i < nv; ++i) { centre.x += verts[i * 3] / nv; centre.y += verts[i * 3 + 1] / nv; centre.z += verts[i * 3 + 2] / nv; }
+    for (int64_t i = 0; i < nf; ++i) { V3 c = cross(sub(vert(i, 1), vert(i, 0)), sub(vert(i, 2), vert(i, 0))); acc += 0.5 * std::sqrt(dot(c, c)); cdf[i] = acc; }
+    long long tot_nodes = 0, tot_tris = 0, hits = 0, max_sp = 0;
+    std::vector<uint32_t> stack(256);
+    for (int r = 0; r < n_rays; ++r) {
+        const int64_t fi = std::lower_bound(cdf.begin(), cdf.end(), U(rng) * acc) - cdf.begin();
+        float a = U(rng), b = U(rng);
+        if (a + b > 1.f) { a = 1.f - a; b = 1.f - b; }
+        V3 p0 = vert(fi, 0), e1 = sub(vert(fi, 1), p0), e2 = sub(vert(fi, 2), p0);
+        V3 o{p0.x + a * e1.x + b * e2.x, p0.y + a * e1.y + b * e2.y, p0.z + a * e1.z + b * e2.z};
+        V3 n = cross(e1, e2);
+        float nl = std::sqrt(dot(n, n));
+        n = {n.x / nl, n.y / nl, n.z / nl};
+        if (dot(n, sub(centre, o)) < 0) n = {-n.x, -n.y, -n.z};
+        V3 t = std::fabs(n.x) > 0.1f ? V3{0, 1, 0} : V3{1, 0, 0};
+        V3 bx = cross(t, n); float bl = std::sqrt(dot(bx, bx)); bx = {bx.x / bl, bx.y / bl, bx.z / bl};
+        V3 by = cross(n, bx);
+        const float u0 = U(rng), u1 = U(rng), rr = std::sqrt(u0), ph = 6.2831853f * u1, cz = std::sqrt(std::max(0.f, 1.f - u0));
+        V3 d{bx.x * rr * std::cos(ph) + by.x * rr * std::sin(ph) + n.x * cz, bx.y * rr * std::cos(ph) + by.y * rr * std::sin(ph) + n.y * cz,
+             bx.z * rr * std::cos(ph) + by.z * rr * std::sin(ph) + n.z * cz};
+        o = {o.x + 8.94e-5f * d.x, o.y + 8.94e-5f * d.y, o.z + 8.94e-5f * d.z};
+        const float id[3] = {1.f / d.x, 1.f / d.y, 1.f / d.z}, oo[3] = {o.x, o.y, o.z};
+        float best = INFINITY;
+        int sp = 0;
+        uint32_t cur = 0;   // node index, or 0x80000000 | start << 3 | count
+        for (;;) {
+            if (cur & 0x80000000u) {
+                const int start = (cur & 0x7fffffffu) >> 3, cnt = cur & 7;
+                for (int k = 0; k < cnt; ++k) {
+                    ++tot_tris;
+                    const int64_t ti = bvh.tri_order[start + k];
+                    V3 q0 = vert(ti, 0), f1 = sub(vert(ti, 1), q0), f2 = sub(vert(ti, 2), q0);
+                    V3 pv = cross(d, f2); float det = dot(f1, pv); float inv = 1.f / det;
+                    V3 tv = sub(o, q0); float uu = dot(tv, pv) * inv; V3 qv = cross(tv, f1); float vv = dot(d, qv) * inv; float tt = dot(f2, qv) * inv;
+                    if (uu >= 0 && vv >= 0 && uu + vv <= 1 && tt >= 0 && tt < best) best = tt;
+                }
+                if (!sp) break;
+                cur = stack[--sp];
+                continue;
+            }
+            ++tot_nodes;
+            const WideNode& w = bvh.nodes[cur];
+            float key[4]; uint32_t ref[4]; int m = 0;
+            for (int s = 0; s < w.n; ++s) {
+                float tn = 0.f, tf = best;
+                for (int k = 0; k < 3; ++k) {
+                    float t0 = (q[cur].lo[s][k] - oo[k]) * id[k], t1 = (q[cur].hi[s][k] - oo[k]) * id[k];
+                    if (t0 > t1) std::swap(t0, t1);
+                    tn = std::max(tn, t0); tf = std::min(tf, t1);
+                }
+                if (tn <= tf) { key[m] = tn; ref[m] = w.child[s] >= 0 ? (uint32_t)w.child[s] : (0x80000000u | (uint32_t)w.leaf_start[s] << 3 | (uint32_t)w.leaf_count[s]); ++m; }
+            }
+            for (int i = 1; i < m; ++i) for (int j = i; j > 0 && key[j] < key[j - 1]; --j) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
+            if (m == 0) { if (!sp) break; cur = stack[--sp]; continue; }
+            for (int i = m - 1; i >= 1; --i) stack[sp++] = ref[i];
+            max_sp = std::max<long long>(max_sp, sp);
+            cur = ref[0];
+        }
+        hits += best < INFINITY;
+    }
+    size_t leaves = 0, leaf_tris = 0, children = 0;
+    for (const auto& w : bvh.nodes) for (int s = 0; s < w.n; ++s) { ++children; if (w.child[s] < 0) { ++leaves; leaf_tris += w.leaf_count[s]; } }
+    printf("{\"triangles\": %lld, \"nodes\": %zu, \"depth\": %d, \"sah\": %.3f, \"build_s\": %.2f, \"children_per_node\": %.3f, \"tris_per_leaf\": %.3f, "
+           "\"rays\": %d, \"hit_frac\": %.4f, \"nodes_per_ray\": %.3f, \"tris_per_ray\": %.3f, \"max_stack\": %lld}\n",
+           (long long)nf, nn, bvh.depth, bvh.sah_cost, build_s, (double)children / nn, (double)leaf_tris / leaves, n_rays, (double)hits / n_rays,
+           (double)tot_nodes / n_rays, (double)tot_tris / n_rays, max_sp);
+    return 0;
+}

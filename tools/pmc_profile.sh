@@ -1,17 +1,20 @@
 #!/bin/bash
-# PMC passes for the bake kernels (run on the GPU box via gpurun).  Counters are collected in their own runs
-# (no --kernel-trace/--stats mixing), one pass per counter group; summaries land in gpurun_out/pmc_<tag>/summary.txt
-# usage: tools/pmc_profile.sh <tag> [bench args...]
+# rocprofv3 passes for the bake kernels (run on the GPU box via gpurun).  One kernel-trace pass (durations), then one pass per counter
+# group -- counters are collected in their own runs, never mixed with tracing.  Per-dispatch means land in gpurun_out/pmc_<tag>/summary.txt
+# and, with the source hash of the kernels they were taken on, in gpurun_out/pmc_<tag>/pmc.json (bench.py reads profiles/pmc_r2.json).
+# usage: [IRIS_HIP_LIB=...] tools/pmc_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---lobes 6 --steps 1 --warmup 0 --cpu-seconds 0 --no-roofline}
+ARGS=${@:---steps 3 --warmup 1 --views 1 --cpu-seconds 0 --no-roofline}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 i=0
 for GROUP in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-  "SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE" \
+  "SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE" \
+  "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU2" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
   "FETCH_SIZE" \
   "WRITE_SIZE TCP_TCC_READ_REQ_sum" \
@@ -20,5 +23,5 @@ for GROUP in \
   i=$((i+1))
   rocprofv3 --pmc $GROUP --output-format csv -d $OUT/pass$i -- python3 bench.py $ARGS > $OUT/pass$i.log 2>&1
 done
-python3 tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 tools/pmc_summary.py $OUT "$ARGS" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
