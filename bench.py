@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--lobes", type=str, default="0,1,2,3,4,5,6", help="0 = diffuse, 1..6 = specular roughness levels")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg-5 (path_tracing_single fwd+bwd) measurement appended under `extras`")
     ap.add_argument("--pixel-block", type=int, default=8, help="order valid pixels in BxB image blocks (0 = row-major)")
     ap.add_argument("--per-lobe", action="store_true", help="one launch per lobe (spread over --streams) instead of the single-launch view kernel")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over (--per-lobe)")
@@ -305,13 +306,14 @@ def main():
             c, pr = pj["counters"], pj["rays_per_launch"]
             clock = c["GRBM_GUI_ACTIVE"] / 8 / (pj["duration"]["avg_ns"] * 1e-9)          # shader clock the kernel held in the profiled run (Hz)
             cal = pj["calibration"]
-            # VALU issue.  gfx950 issues `fast` VALU instructions (v_fma_f32, v_mul/add/sub_f32, v_add_u32, v_and/or_b32, v_mov_b32, v_lshrrev_b32) at 2 cycles
-            # per wave64 and pairs them with other work; every other VALU instruction (v_fma_mix, v_perm, v_cndmask, v_cmp, v_min/max, v_cvt ...) holds
-            # the SIMD's issue for 4 cycles, transcendentals for 8 (tools/microbench valu: 905 vs 520-590 vs 295 G wave-inst/s chip-wide).  The roof of an
-            # instruction stream whose complex share is >= 1/2 is therefore complex_instructions x 4 cycles <= SIMD cycles.
-            cf = cal["complex_frac"]
+            # VALU issue.  A SIMD issues VALU work in quad-cycles: an instruction holds one (a transcendental two), and gfx950 can pair two `fast`
+            # instructions (v_fma_f32, v_mul/add/sub_f32, v_add_u32, v_and/or_b32, v_mov_b32, v_lshrrev_b32: 2 cycles per wave64, 905 G wave-inst/s chip-wide
+            # in tools/microbench against 520-590 for everything else) in one.  SQ_ACTIVE_INST_VALU counts the instruction quad-cycles (= SQ_INSTS_VALU +
+            # SQ_INSTS_VALU_TRANS_F32 in the profile), SQ_ACTIVE_INST_VALU2 those in which two issued together: their difference is the number of quad-cycles
+            # a SIMD's VALU issue was occupied, and the roof is one per SIMD per 4 shader cycles.
             valu_inst_per_ray = c["SQ_INSTS_VALU"] / pr
-            valu_ach = valu_inst_per_ray * cf * rate / 1e9                       # G complex-issue slots / s
+            quads_per_ray = (c["SQ_ACTIVE_INST_VALU"] - c["SQ_ACTIVE_INST_VALU2"]) / pr
+            valu_ach = quads_per_ray * rate / 1e9                                # G issue quad-cycles / s
             valu_peak = N_SIMD * clock / 4 / 1e9
             # vector-memory path (TA / L1): a wave64 load that touches n distinct 64-B lines costs the CU's TA max(9.9, 3.5 + 0.39 n) cycles when it hits L1
             # (tools/microbench gather: 28.1 cycles at 64 lines, 16.1 at 32, 9.9 at <= 16); lines per load = TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD,
@@ -328,8 +330,9 @@ def main():
             traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
             hbm_ach = traffic / pr * rate / 1e9
             roofs = {
-                "valu": {"achieved": round(valu_ach, 1), "peak": round(valu_peak, 1), "unit": "G complex-issue slots/s", "frac": round(valu_ach / valu_peak, 4),
-                         "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "complex_issue_share": cf, "profiled_clock_GHz": round(clock / 1e9, 3),
+                "valu": {"achieved": round(valu_ach, 1), "peak": round(valu_peak, 1), "unit": "G VALU issue quad-cycles/s", "frac": round(valu_ach / valu_peak, 4),
+                         "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "issue_quads_per_ray": round(quads_per_ray, 1),
+                         "dual_issued_share_of_instructions": round(2 * c["SQ_ACTIVE_INST_VALU2"] / c["SQ_INSTS_VALU"], 3), "profiled_clock_GHz": round(clock / 1e9, 3),
                          "simd_lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"] * 64, 1), 3)},
                 "l1_ta": {"achieved": round(ta_ach, 1), "peak": round(ta_peak, 1), "unit": "G TA cycles/s", "frac": round(ta_ach / ta_peak, 4),
                           "wave_loads_per_ray": round(loads_per_ray, 2), "lines_per_wave_load": round(lines_per_load, 1), "ta_cycles_per_wave_load": round(cyc_load, 1),
@@ -395,6 +398,11 @@ def main():
                                   "calibration_mrays_per_s_by_threads": calib,
                                   "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, OpenMP x{threads}"}
         result["gpu_over_cpu"] = round(value / (n / dtc / 1e6), 1)
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- extras: BASELINE configs[4] (train_brdf_crf / train_emitter inner loop: differentiable one-bounce path tracer, SPP 32) on the same scene
+        from tools import bench_pt_single
+        result["extras"] = {"cfg5_path_tracing_single": bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2)}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

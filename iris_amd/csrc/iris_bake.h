@@ -179,12 +179,6 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU): 7 x 20 488 B of LDS, 72 VGPRs.
 #define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s
 #endif
-#ifndef IRIS_LDS_NODES           // top-of-tree nodes staged in LDS per workgroup (80 B each; 0 = none).  21 = 3 levels of a full BVH4, 85 = 4, 341 = 5
-#define IRIS_LDS_NODES 0
-#endif
-#ifndef IRIS_MERGE_TAIL          // 1: the unfinished rays a tile's waves are left with when the ray list runs dry are finished together by one
-#define IRIS_MERGE_TAIL 1        // wave (tile_sort_trace's merged tail) instead of by every wave alone
-#endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
 #define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
 #endif
@@ -200,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 //   once per tile and was measured 9 % slower per fence pair).
 template <bool SPEC, bool COUNT, int LAYOUT, int TILE_STACK>
 __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
-                                          uint32_t* ovf, const uint4* s_top, TileTail* s_tail, TraceStats& ts, uint32_t& n_rays) {
+                                          uint32_t* ovf, TraceStats& ts, uint32_t& n_rays) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
     float2* res_g = reinterpret_cast<float2*>(res + kTileRays);   // GGX weights (g1, g0): second array of the slab
@@ -213,8 +207,8 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     const int nr = np * spp;
 
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
-    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true, IRIS_LDS_NODES, IRIS_MERGE_TAIL != 0>(
-        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, s_top, s_tail, ts,
+    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
+        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
         [&](int r) -> uint32_t {
             const int pl = r / spp, s = r - pl * spp;
             const int64_t p = p0 + pl;
@@ -242,6 +236,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     // bake_shading.py:121-122, :184-185 -> Le * g) and take the per-pixel mean in the fixed order of the pixel-per-wave kernel
     // (lane-strided partial sums, xor butterfly)
     const int n_groups = (np + ppw - 1) / ppw;
+    IRIS_PHASE_BEGIN();
     for (int g = wave; g < n_groups; g += kBlock / 64) {
         const int pl = g * ppw + sub;
         const bool pvalid = pl < np;
@@ -280,6 +275,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
             if (SPEC) st3(a.out1 + p * 3, mk3(a1x * inv_spp, a1y * inv_spp, a1z * inv_spp));
         }
     }
+    IRIS_PHASE_MARK(3);
 }
 
 // XCD-aware tile queue.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx & 7), each with its own L2: every XCD draws from its
@@ -313,11 +309,8 @@ __global__ __launch_bounds__(kBlock, COUNT ? 4 : IRIS_TILE_WAVES) void bake_tile
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
-    __shared__ uint4 s_top[IRIS_LDS_NODES > 0 ? IRIS_LDS_NODES * kLdsNodeQuads : 1];
-    __shared__ TileTail s_tail;
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
-    if (IRIS_LDS_NODES > 0) stage_top_nodes(a.sc, s_top, IRIS_LDS_NODES);   // published by the first barrier of the tile loop
     constexpr int NC = SPEC ? 2 : 1;
     float4* res = a.scratch + (size_t)blockIdx.x * kTileRays * NC;
     uint32_t* ovf = a.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform (Stack adds the lane)
@@ -331,7 +324,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? 4 : IRIS_TILE_WAVES) void bake_tile
         __syncthreads();
         const int64_t tile = s_tile;
         if (tile >= n_tiles) break;
-        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, s_top, &s_tail, ts, n_rays);
+        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
     }
     flush_stats<COUNT>(a, ts, n_rays);
 }
@@ -357,11 +350,8 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
-    __shared__ uint4 s_top[IRIS_LDS_NODES > 0 ? IRIS_LDS_NODES * kLdsNodeQuads : 1];
-    __shared__ TileTail s_tail;
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
-    if (IRIS_LDS_NODES > 0) stage_top_nodes(v.base.sc, s_top, IRIS_LDS_NODES);   // published by the first barrier of the tile loop
     float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
     uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform; no private scratch in this kernel
     for (;;) {
@@ -377,8 +367,8 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
         a.spp = v.lobe[l].spp; a.rough = v.lobe[l].rough; a.stream_id = v.lobe[l].stream_id; a.tile_px = v.lobe[l].tile_px;
         a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr; a.src_next = nullptr;
         TraceStats ts; uint32_t n_rays = 0;   // unused (COUNT = false)
-        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, s_top, &s_tail, ts, n_rays);
-        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, s_top, &s_tail, ts, n_rays);
+        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
+        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
     }
 }
 

@@ -111,7 +111,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
                                        iris_scene** out) {
     API_BEGIN
     if (!out || nv < 0 || nf < 0 || (nf > 0 && (!verts || !faces))) return fail(IRIS_ERR_ARG, "iris_scene_create: bad arguments");
-    if (nf >= (1 << 26)) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^26 triangles (32-bit byte offsets into the 64-B records)");
+    if (nf >= (1 << 26) - 1) return fail(IRIS_ERR_ARG, "iris_scene_create: more than 2^26 triangles (32-bit byte offsets into the 64-B records)");
     for (int64_t i = 0; i < nf * 3; ++i)
         if (faces[i] < 0 || faces[i] >= nv) return fail(IRIS_ERR_ARG, "iris_scene_create: face index out of range");
     if (layout == IRIS_BVH_DEFAULT) layout = IRIS_BVH4_Q8;
@@ -126,8 +126,12 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
 
     // ---- encode nodes ----
     const size_t nn = bvh.nodes.size();
+    // Unused child slots carry an inverted quantised box, which the slab test rejects -- except when the planes of a tiny node far from
+    // the ray origin collapse onto one t (b absorbs q * a): their reference is therefore a 1-triangle leaf on a degenerate record appended
+    // to the triangle table (all zeros: det = 0, never accepted), never kEmptyRef, which the traversal also uses as "lane idle".
+    const uint32_t dummy_leaf = kLeafBit | ((uint32_t)bvh.tri_order.size() << 3) | 1u;
     auto child_ref = [&](const WideNode& w, int s) -> uint32_t {
-        if (s >= w.n) return kEmptyRef;
+        if (s >= w.n) return dummy_leaf;
         if (w.child[s] >= 0) return (uint32_t)w.child[s];
         return kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
     };
@@ -184,7 +188,8 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     // ---- encode leaf triangles (64 B, one per 64-B line): p0, e1 = p1 - p0, e2 = p2 - p0 (f32 subtractions, exactly what the
     // Moeller-Trumbore contract computes), original index, then p1, p2 for the hit point ----
     const size_t nt = bvh.tri_order.size();
-    std::vector<float> tris(std::max<size_t>(nt, 1) * 16, 0.f);
+    std::vector<float> tris((nt + 1) * 16, 0.f);      // + the degenerate record unused child slots point to (id -1)
+    { const int32_t none = -1; std::memcpy(&tris[nt * 16 + 9], &none, 4); }
     for (size_t i = 0; i < nt; ++i) {
         int32_t f = bvh.tri_order[i];
         float* p = tris.data() + i * 16;
@@ -211,7 +216,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     s->dev.phase_min = kPhaseMin;
     if (g_opt_phase_min >= 0) s->dev.phase_min = (int)g_opt_phase_min;  // iris_debug_set("phase_min") (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
-    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth; s->info.lds_nodes = layout == IRIS_BVH4_Q8 ? IRIS_LDS_NODES : 0;
+    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth;
     s->info.sah_cost = bvh.sah_cost;
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
@@ -673,6 +678,8 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     if (!sc || !em || !slf || P < 0 || spp < 1 || (P > 0 && (!pos || !nrm || !out0 || (spec && (!wo || !out1)))))
         return fail(IRIS_ERR_ARG, "iris_bake: bad arguments");
     if (variant < IRIS_BAKE_AUTO || variant > IRIS_BAKE_TILE_SORTED) return fail(IRIS_ERR_ARG, "iris_bake: unknown kernel variant");
+    if (em->dev.nf != sc->info.n_triangles)      // eval_emitter indexes is_emitter / emitter_idx by the hit triangle (model/emitter.py:196-203)
+        return fail(IRIS_ERR_ARG, "iris_bake: the emitter tables were built for a mesh with a different number of triangles than the scene");
     if (P == 0) return IRIS_OK;
     BakeArgs a{};
     a.sc = sc->dev; a.em = em->dev; a.slf = slf->dev;
@@ -732,6 +739,8 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     if (!sc || !em || !slf || P < 0 || n_lobes < 1 || n_lobes > kMaxLobes || !roughness || !spp || !stream_ids || !out0 || !out1 ||
         (P > 0 && (!pos || !nrm || !wo)))
         return fail(IRIS_ERR_ARG, "iris_bake_view: bad arguments");
+    if (em->dev.nf != sc->info.n_triangles)
+        return fail(IRIS_ERR_ARG, "iris_bake_view: the emitter tables were built for a mesh with a different number of triangles than the scene");
     if (P == 0) return IRIS_OK;
     const uint64_t need = iris_bake_workspace_bytes(P, 1, 1);
     if (!workspace || workspace_bytes < need) return fail(IRIS_ERR_ARG, "iris_bake_view: workspace of iris_bake_workspace_bytes() bytes required");
@@ -792,6 +801,16 @@ extern "C" IRIS_API int iris_debug_bake_specular(const iris_scene* sc, const iri
     return bake_launch(true, sc, em, slf, pos, nrm, wo, roughness, P, spp, u2, seed, stream_id, pix_id, Ls0, Ls1, tri_next, src_next, stats, variant,
                        workspace, workspace_bytes, stream);
 }
+
+#ifdef IRIS_PHASE_TIMING
+// diagnostic build only (tools/diag_phases.py): read / reset the per-phase cycle sums of the tile kernels
+extern "C" IRIS_API int iris_debug_phase_cycles(unsigned long long* out8, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(iris::g_phase_cycles), 64));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(iris::g_phase_cycles), z, 64)); }
+    return IRIS_OK;
+}
+#endif
 
 // ======================================================================================================
 // a9 (cfg 5): path_tracing_single building blocks and stages (iris_pt.h)

@@ -36,14 +36,8 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
 // (scratch) array or -- GLOBAL_OVF, kernels that must not use scratch -- in a workgroup-private slab of the caller's workspace
 // laid out [entry][thread] so that the rare accesses coalesce.
 constexpr int kStackCapacity = kStackLds + kStackSpill;
-// LDS_NODES > 0: the first LDS_NODES nodes of the table (breadth-first order = the top of the tree, visited by every ray) are staged in
-// LDS as kLdsNodeStride-byte records (`top`); node_step reads them with ds_read_b128 instead of going through the vector-memory path.
-constexpr int kLdsNodeQuads = 5;   // 64-B node + 16 B of padding: an 80-B stride spreads lane-divergent ds_read_b128 over the banks
-                                   // (tools/microbench: 8.0 cycles per read against 16.3 at a 64-B stride, 16 waves per CU, one lane per node)
-template <int LDS_DEPTH, bool GLOBAL_OVF = false, int LDS_NODES = 0>
+template <int LDS_DEPTH, bool GLOBAL_OVF = false>
 struct Stack {
-    static constexpr int kLdsNodes = LDS_NODES;
-    const uint4* top;  // LDS_NODES > 0: the staged nodes
     uint32_t* lds;  // &s_stack[threadIdx.x]
     uint32_t* ovf;  // GLOBAL_OVF: the workgroup's slab (wave-uniform: stays in scalar registers; the lane offset is added at the rare use)
     uint32_t spill[GLOBAL_OVF ? 1 : kStackCapacity - LDS_DEPTH];
@@ -148,14 +142,8 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
     const bool px = r.px, py = r.py, pz = r.pz;
     if (LAYOUT == kLayoutQ8) {
         // 32-bit byte offset from the (scalar) table base: one shift instead of a 64-bit shift + add per visit (the node table is < 4 GB)
-        uint4 hd, q1, q2, rf;
-        if (STACK::kLdsNodes > 0 && r.cur < (uint32_t)STACK::kLdsNodes) {
-            const uint4* n = st.top + r.cur * kLdsNodeQuads;
-            hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3];
-        } else {
-            const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
-            hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3];
-        }
+        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
+        const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
         // per-axis: t(q) = q * 2^e * idir + (origin * idir - o * idir); the node stores 2^(e+24) as a float (see below)
         const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
@@ -219,7 +207,7 @@ template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
     RayState r;
     ray_begin(r, o, d);
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.top = nullptr; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
@@ -266,22 +254,14 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 #define IRIS_REFILL_MIN 48
 #endif
 constexpr int kRefillMin = IRIS_REFILL_MIN;
-//   resume(r, st)        : called right after a lane's ray has been set up (ray_begin, empty stack): may restore a traversal that was
-//                          parked half-way -- best hit so far, current node / leaf reference, stack contents
-//   park(r, st)          : TAIL_MAX > 0 only.  Once the list is exhausted and at most TAIL_MAX lanes of the wave still hold an
-//                          unfinished ray, those lanes hand their traversal state back through park() and the wave returns: the
-//                          caller finishes the parked rays of all its waves together (tile_sort_trace's merged tail) instead of
-//                          letting every wave run its last few long rays alone at a few % lane utilisation.  Per-ray results do
-//                          not change: the same node / leaf steps are executed, by another lane.
-constexpr int kTailMax = 16;
-template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, int LDS_NODES, int TAIL_MAX, class Fetch, class Prepare, class Retire, class Resume, class Park>
-__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, const uint4* top, TraceStats* ts, Fetch fetch,
-                                             Prepare prepare, Retire retire, Resume resume, Park park) {
+template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire>
+__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
+                                             Retire retire) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(r, r.o, r.d);
     r.cur = kEmptyRef;
-    Stack<LDS_DEPTH, GLOBAL_OVF, LDS_NODES> st; st.lds = lds_stack; st.ovf = ovf; st.top = top; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
     unsigned long long pend = 0;   // wave-uniform: lanes whose next ray has been requested but not activated
@@ -294,7 +274,6 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 prepare(r.o, r.d);
                 ray_begin(r, r.o, r.d);
                 st.sp = 0;
-                resume(r, st);
                 if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
             }
             pend = 0;
@@ -311,16 +290,9 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             pend = __ballot(got);
             if (pend == 0) more = false;
         }
-        {
-            const int n_act = __popcll(__ballot(r.cur != kEmptyRef));
-            if (n_act == 0) {
-                if (pend == 0 && !more) break;
-                continue;
-            }
-            if (TAIL_MAX > 0 && !more && pend == 0 && n_act <= TAIL_MAX) {      // the tail: hand the unfinished rays back
-                if (r.cur != kEmptyRef) { park(r, st); live = false; }
-                break;
-            }
+        if (__ballot(r.cur != kEmptyRef) == 0) {
+            if (pend == 0 && !more) break;
+            continue;
         }
         // ---------------- node phase
         for (;;) {

@@ -6,7 +6,7 @@ OUT=$1; STEPS=$2; shift 2
 mkdir -p $OUT
 for LIB in "$@"; do
   name=$(basename $LIB .so)$AB_TAG
-  IRIS_HIP_LIB=$PWD/$LIB timeout 300 python3 bench.py --steps $STEPS --warmup 2 --no-roofline --cpu-seconds 0 $AB_ARGS > $OUT/$name.json 2> $OUT/$name.err
+  IRIS_HIP_LIB=$PWD/$LIB timeout 300 python3 bench.py --steps $STEPS --warmup 2 --no-roofline --no-extras --cpu-seconds 0 $AB_ARGS > $OUT/$name.json 2> $OUT/$name.err
   python3 - "$OUT/$name.json" "$name" <<'PY'
 import json, sys
 try:

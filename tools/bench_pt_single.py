@@ -16,20 +16,12 @@ class GpuStub(torch.nn.Module):
                 "metallic": 0.5 + 0.5 * torch.sin(x[:, 2:3] * 2.3)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays", type=int, default=8192); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--calls", type=int, default=4)
-    ap.add_argument("--tris", type=int, default=1_000_000)
-    args = ap.parse_args()
-    import bench
+def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp=32, calls=4):
+    """-> dict: Mpaths/s of `steps` training steps (each `calls` forward calls + one backward) on an existing bench workload"""
     from iris_amd.model.emitter import SLFEmitterLearn
-    from iris_amd.utils.path_tracing import path_tracing_single, Scene
+    from iris_amd.utils.path_tracing import path_tracing_single
     from iris_amd.utils.dataset import real_ldr
     from tools import synth
-    dev = torch.device("cuda:0")
-    ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
-    room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
     import tempfile
     tmp = tempfile.mkdtemp()
     ep, sp = os.path.join(tmp, "emitter.pth"), os.path.join(tmp, "vslf.npz")
@@ -42,29 +34,43 @@ def main():
     K, c2w = synth.camera(H, W, 0)
     o, d, dx, dy = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, True, device=dev)
     g = torch.Generator(device="cpu").manual_seed(0)
-    pick = torch.randint(0, H * W, (args.rays,), generator=g).to(dev)
+    pick = torch.randint(0, H * W, (rays,), generator=g).to(dev)
     o, d, dx, dy = o[pick], d[pick], dx[pick], dy[pick]
     mat = GpuStub()
-    target = torch.rand(args.rays, 3, device=dev)
+    target = torch.rand(rays, 3, device=dev)
 
     def step():
         em.radiance.grad = None
         loss = 0
-        for _ in range(args.calls):
-            L = path_tracing_single(scene, em, mat, o, d, dx, dy, args.spp)
+        for _ in range(calls):
+            L = path_tracing_single(scene, em, mat, o, d, dx, dy, spp)
             loss = loss + ((L - target) ** 2).mean()
         loss.backward()
         return loss
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    paths = args.steps * args.calls * args.rays * args.spp
-    print(json.dumps({"metric": "path_tracing_single fwd+bwd", "value": round(paths / dt / 1e6, 2), "unit": "Mpaths/s", "ms_per_step": round(dt / args.steps * 1e3, 2),
-                      "config": {"rays": args.rays, "spp": args.spp, "calls_per_step": args.calls, "triangles": int(room["faces"].shape[0]), "material": "closed-form stub (NGPBRDF is third party)"},
-                      "grad_nonzero_rows": int((em.radiance.grad.abs().sum(-1) > 0).sum())}))
+    paths = steps * calls * rays * spp
+    return {"metric": "path_tracing_single fwd+bwd (BASELINE configs[4]: train_emitter.py:181-189)", "value": round(paths / dt / 1e6, 2), "unit": "Mpaths/s",
+            "ms_per_step": round(dt / steps * 1e3, 2),
+            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "triangles": int(room["faces"].shape[0]), "material": "closed-form stub (NGPBRDF is third party)"},
+            "grad_nonzero_rows": int((em.radiance.grad.abs().sum(-1) > 0).sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=8192); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--calls", type=int, default=4)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    args = ap.parse_args()
+    import bench
+    dev = torch.device("cuda:0")
+    ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
+    room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
+    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls)))
 
 
 if __name__ == "__main__":
