@@ -36,9 +36,13 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
 // (scratch) array or -- GLOBAL_OVF, kernels that must not use scratch -- in a workgroup-private slab of the caller's workspace
 // laid out [entry][thread] so that the rare accesses coalesce.
 constexpr int kStackCapacity = kStackLds + kStackSpill;
+// The LDS part is addressed through an address-space-3 pointer: with a generic pointer hipcc merges the LDS and the overflow path of
+// pop() into one flat_load_dword (a vector-memory instruction with an aperture check, counted on vmcnt AND lgkmcnt) -- on the dependent
+// chain of every pop; with the qualified pointer it is a ds_read_b32 and the overflow a global_load behind a (rare) branch.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 template <int LDS_DEPTH, bool GLOBAL_OVF = false>
 struct Stack {
-    uint32_t* lds;  // &s_stack[threadIdx.x]
+    lds_u32* lds;   // &s_stack[threadIdx.x]
     uint32_t* ovf;  // GLOBAL_OVF: the workgroup's slab (wave-uniform: stays in scalar registers; the lane offset is added at the rare use)
     uint32_t spill[GLOBAL_OVF ? 1 : kStackCapacity - LDS_DEPTH];
     int sp;
@@ -207,7 +211,7 @@ template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
     RayState r;
     ray_begin(r, o, d);
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
@@ -261,7 +265,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(r, r.o, r.d);
     r.cur = kEmptyRef;
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = lds_stack; st.ovf = ovf; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
     unsigned long long pend = 0;   // wave-uniform: lanes whose next ray has been requested but not activated
