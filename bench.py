@@ -383,7 +383,7 @@ def main():
         for th in sorted({max(1, ncpu // d) for d in (1, 2, 4, 8)}):
             oracle.set_num_threads(th)
             cpu_run(max(th * 8, 64))
-            n, dtc = cpu_run(max(th * 16, 128))
+            n, dtc = cpu_run(max(th * 48, 512))
             calib[th] = round(n / dtc / 1e6, 3)
         threads = max(calib, key=calib.get)
         oracle.set_num_threads(threads)

@@ -26,6 +26,7 @@ class VoxelSLF(nn.Module):
         self._h = None
         self._h_device = None
         self._ver = None
+        self._rver = None
 
     # -- device handle ---------------------------------------------------------------------------------
     def refresh(self):
@@ -34,20 +35,29 @@ class VoxelSLF(nn.Module):
         if h:
             L.lib().iris_slf_destroy(h)
 
-    def handle(self, device):
-        """Device-side tables (int32 index grid + padded radiance rows).  Rebuilt whenever `inds` / `radiance` changed since the
-        upload (load_state_dict through a parent module, in-place edits, scatter_add), so a cached handle never goes stale."""
+    @staticmethod
+    def _tver(t):
+        return (t._version, t.data_ptr(), str(t.device), tuple(t.shape))
+
+    def handle(self, device, need_radiance=True):
+        """Device-side tables (int32 index grid + padded radiance rows).  They follow the module: the tables are rebuilt when `inds`
+        changed since the upload (load_state_dict through a parent module, in-place edits, .to()), and the radiance rows alone are
+        re-uploaded when only `radiance` did (scatter_add, mean pooling) -- lazily, the next time a lookup needs them."""
         device = torch.device(device)
-        ver = tuple((t._version, t.data_ptr(), str(t.device), tuple(t.shape)) for t in (self.inds, self.radiance))
-        if self._h is None or self._h_device != device or self._ver != ver:
+        iv = self._tver(self.inds)
+        if self._h is None or self._h_device != device or self._ver != iv:
             self.refresh()
-            self._ver = ver
             inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
             rad = L.host_f32(self.radiance).reshape(-1, 3)
             h = C.c_void_p()
             L.check(L.lib().iris_slf_create(inds.ctypes.data_as(C.c_void_p), self.H, rad.ctypes.data_as(C.c_void_p), rad.shape[0],
                                             self.voxel_min, self.voxel_max, device.index or 0, C.byref(h)))
-            self._h, self._h_device = h, device
+            self._h, self._h_device, self._ver, self._rver = h, device, iv, self._tver(self.radiance)
+        elif need_radiance and self._rver != self._tver(self.radiance):
+            rr = self.radiance.detach().to(device=device, dtype=torch.float32).contiguous()
+            with torch.cuda.device(device):
+                L.check(L.lib().iris_slf_set_radiance(self._h, L.ptr(rr), rr.shape[0], L.stream()))
+            self._rver = self._tver(self.radiance)
         return self._h
 
     def load_state_dict(self, *a, **k):
@@ -88,6 +98,6 @@ class VoxelSLF(nn.Module):
         acc = L.require_gpu(self.radiance, torch.float32, "VoxelSLF.radiance buffer")
         cnt = L.require_gpu(self.count, torch.int64, "VoxelSLF.count buffer")
         with torch.cuda.device(x.device):
-            L.check(L.lib().iris_slf_scatter_add(self.handle(x.device), L.ptr(x), L.ptr(radiance), x.shape[0], L.ptr(acc), L.ptr(cnt), L.stream()))
+            L.check(L.lib().iris_slf_scatter_add(self.handle(x.device, need_radiance=False), L.ptr(x), L.ptr(radiance), x.shape[0], L.ptr(acc), L.ptr(cnt), L.stream()))
         # the kernel wrote the buffers behind torch's back: bump their version counters so that handle() re-uploads them
         self.radiance.add_(0); self.count.add_(0)

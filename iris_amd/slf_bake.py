@@ -21,21 +21,30 @@ from .utils.path_tracing import ray_intersect
 
 
 def _hits(scene, batch, device):
-    rays = batch["rays"].to(device)
-    positions, _, _, idx, valid = ray_intersect(scene, rays[..., :3].contiguous(), rays[..., 3:6].contiguous())
-    return positions, idx, valid
+    """Primary hits of one view.  The reference re-traces every view in each of its passes (bounds, histogram, pooling); here the
+    result is kept with the batch (a few tens of MB per 1080p view against 288 GB), so a view is traced once."""
+    hit = batch.get("_iris_hits") if isinstance(batch, dict) else None
+    if hit is None or hit[0].device != torch.device(device) or hit[3] is not scene:
+        rays = batch["rays"].to(device)
+        positions, _, _, idx, valid = ray_intersect(scene, rays[..., :3].contiguous(), rays[..., 3:6].contiguous())
+        hit = (positions, idx, valid, scene)
+        if isinstance(batch, dict):
+            batch["_iris_hits"] = hit
+    return hit[0], hit[1], hit[2]
 
 
 def scene_bounds(scene, views, dataset, device):
     """slf_bake.py:69-93 including its scannetpp centre (``voxel_c = voxel_min + voxel_max``, not halved: kept, the files depend on it)."""
-    voxel_min, voxel_max = 1000., 0.0
+    # running min / max stay on the device (one host sync at the end instead of three per view); misses are masked out with the
+    # identities of the reference's start values (1000, 0)
+    lo = torch.tensor(1000.0, device=device)
+    hi = torch.tensor(0.0, device=device)
     for batch in views:
         positions, _, valid = _hits(scene, batch, device)
-        if not valid.any():
-            continue
-        position = positions[valid]
-        voxel_min = min(voxel_min, position.min())
-        voxel_max = max(voxel_max, position.max())
+        v = valid[:, None]
+        lo = torch.minimum(lo, torch.where(v, positions, lo).min())
+        hi = torch.maximum(hi, torch.where(v, positions, hi).max())
+    voxel_min, voxel_max = lo.cpu(), hi.cpu()
     if dataset in ("synthetic", "real"):
         voxel_min = 1.1 * voxel_min
         voxel_max = 1.1 * voxel_max
@@ -50,9 +59,7 @@ def visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device):
     hist = torch.zeros(res_spatial, res_spatial, res_spatial, device=device, dtype=torch.float32)
     for batch in views:
         positions, _, valid = _hits(scene, batch, device)
-        if not valid.any():
-            continue
-        voxel_histogram(positions[valid], float(voxel_min), float(voxel_max), res_spatial, hist)
+        voxel_histogram(positions[valid], float(voxel_min), float(voxel_max), res_spatial, hist)      # (an empty selection is a no-op)
     return hist
 
 
@@ -61,11 +68,8 @@ def pool_radiance(scene, views, vslf, device):
     vslf = vslf.to(device)
     for batch in views:
         positions, _, valid = _hits(scene, batch, device)
-        if not valid.any():
-            continue
         vslf.scatter_add(positions[valid], batch["rgbs"].to(device=device, dtype=torch.float32)[valid])
-    vslf.radiance = vslf.radiance / vslf.count[..., None].float().clamp_min(1)
-    vslf.refresh()
+    vslf.radiance = vslf.radiance / vslf.count[..., None].float().clamp_min(1)      # (the handle re-uploads the rows at the next lookup)
     return vslf
 
 
@@ -101,8 +105,6 @@ def extract_emitters(scene, vertices, faces, views, threshold, device="cuda"):
     triangle_count = torch.zeros(n_face, device=device)
     for batch in views:
         _, idx, valid = _hits(scene, batch, device)
-        if not valid.any():
-            continue
         scatter_add_rows(batch["rgbs"].to(device=device, dtype=torch.float32)[valid], idx[valid], triangle_radiance, triangle_count)
     mean = triangle_radiance / triangle_count.unsqueeze(-1).clamp_min(1)
     is_emitter = (torch.max(mean, dim=-1)[0] > threshold).cpu()

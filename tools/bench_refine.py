@@ -64,7 +64,7 @@ def main():
         "f1_refine_diffuse": {"pixels_per_batch": bp, "spp": args.spp, "indir_depth": args.depth, "ms_per_batch": round(t_f1 * 1e3, 2),
                               "Mpaths_per_s": round(bp * args.spp / t_f1 / 1e6, 1), "note": "first-bounce paths (each continues up to indir_depth bounces with NEE)"},
         "f2_bake_slf": {"views": args.views, "pixels": args.views * H * W, "seconds": round(t_slf, 3), "Mpixels_per_s": round(args.views * H * W / t_slf / 1e6, 1),
-                        "occupied_voxels": int(sd["mask"].sum()), "note": "3 passes over the views (bounds, occupancy, pooling), each re-tracing the primary rays as the reference does"},
+                        "occupied_voxels": int(sd["mask"].sum()), "note": "3 passes over the views (bounds, occupancy, pooling); every view is traced once and its hits are kept"},
         "f2_extract_emitters": {"seconds": round(t_em, 3), "Mpixels_per_s": round(args.views * H * W / t_em / 1e6, 1), "emitters": int(em["is_emitter"].sum())}}))
 
 
