@@ -132,12 +132,9 @@ IRIS_API int iris_bake_specular(const iris_scene *, const iris_emitter *, const 
                        uint32_t stream_id, const int32_t *pix_id, float *Ls0, float *Ls1, int64_t *tri_next,
                        void *workspace, uint64_t workspace_bytes, iris_stream_t);
 
-/* All lobes of one view (bake_shading.py:93-204) behind one call: n_lobes <= 8; roughness[l] < 0 selects the
+/* All lobes of one view (bake_shading.py:93-204) in ONE launch with one tile queue: n_lobes <= 8; roughness[l] < 0 selects the
  * diffuse lobe (out1[l] may be NULL), otherwise the specular lobe of that roughness; spp[l] <= iris_bake_tile_max_spp(); Philox uniforms only.
  * roughness / spp / stream_ids / out0 / out1 are HOST arrays.  Outputs are bit-identical to the per-lobe entry points. */
-/* workspace of iris_bake_view: the streamed path's ray / hit buffers (56 B per ray slot of a chunk of <= 2^28 slots);
- * with less (but >= iris_bake_workspace_bytes(P, 1, 1)) the tile kernels of the per-lobe entry points run behind one launch instead */
-IRIS_API uint64_t iris_bake_view_workspace_bytes(int64_t P, int n_lobes, const int32_t *spp);
 IRIS_API int iris_bake_view(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm, const float *wo,
                    const int32_t *pix_id, int64_t P, int n_lobes, const float *roughness, const int32_t *spp,
                    const uint32_t *stream_ids, uint64_t seed, float *const *out0, float *const *out1, void *workspace,

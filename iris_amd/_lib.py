@@ -43,7 +43,6 @@ PROTOTYPES = {
     "iris_slf_lookup": [_P, _P, _I64, _P, _P, _P],
     "iris_eval_emitter": [_P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P],
     "iris_bake_workspace_bytes": [_I64, _I32, _I32],
-    "iris_bake_view_workspace_bytes": [_I64, _I32, _P],
     "iris_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _U64, _P],
     "iris_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _U64, _P],
     "iris_debug_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
@@ -78,7 +77,7 @@ PROTOTYPES = {
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64, "iris_bake_view_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
 
 _lib = None
 

@@ -99,7 +99,7 @@ def bake_specular(scene, emitter, position, normal, wo, roughness, spp, u2=None,
     return (Ls0, Ls1) + ((tri,) if want_tri else ()) + ((src,) if want_src else ())
 
 
-def bake_lobes(scene, emitter, position, normal, wo, roughness, spps, seed=0, stream_ids=None, pix_id=None, streamed=True):
+def bake_lobes(scene, emitter, position, normal, wo, roughness, spps, seed=0, stream_ids=None, pix_id=None):
     """All lobes of one view in ONE launch (`iris_bake_view`): roughness[l] is None for the diffuse lobe, a float otherwise.
     Returns a list with Ld (P,3) for diffuse entries and (Ls0, Ls1) for specular ones -- bit-identical to bake_diffuse /
     bake_specular with the same stream ids (default: 0 for diffuse, 1 + position in linspace(0.02,1,6) otherwise)."""
@@ -120,11 +120,7 @@ def bake_lobes(scene, emitter, position, normal, wo, roughness, spps, seed=0, st
     sid = (C.c_uint32 * n)(*[int(s) for s in stream_ids])
     p0 = (C.c_void_p * n)(*[t.data_ptr() for t in outs0])
     p1 = (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in outs1])
-    if streamed:       # ray / hit buffers of the streamed path (iris_stream.h); streamed=False: the tile kernels behind one launch (same bits)
-        ws_bytes = int(L.lib().iris_bake_view_workspace_bytes(P, n, spp_a))
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-    else:
-        ws, ws_bytes = _workspace(P, 1, True, L.BAKE_AUTO, dev)
+    ws, ws_bytes = _workspace(P, 1, True, L.BAKE_AUTO, dev)
     with torch.cuda.device(dev):
         L.check(L.lib().iris_bake_view(scene.handle, emitter.handle(dev), emitter.slf.handle(dev), L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(pix_id),
                                        P, n, rough, spp_a, sid, int(seed), p0, p1, L.ptr(ws), ws_bytes, L.stream()))

@@ -128,8 +128,11 @@ __device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t 
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: integer multiplies are the slow
+        // instructions of the sampling pass
+        const uint64_t m0 = (uint64_t)0xD2511F53u * (uint64_t)c0, m1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        uint32_t h0 = (uint32_t)(m0 >> 32), l0 = (uint32_t)m0;
+        uint32_t h1 = (uint32_t)(m1 >> 32), l1 = (uint32_t)m1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     }

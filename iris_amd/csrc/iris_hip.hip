@@ -15,7 +15,6 @@
 #include "iris_device.h"
 #include "iris_trace.h"
 #include "iris_bake.h"
-#include "iris_stream.h"
 #include "iris_pt.h"
 #include "iris_cache.h"
 #include "iris_denoise.h"
@@ -41,15 +40,12 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
 
 // ---- diagnostics options (iris_hip_debug.h): process-wide, set by tests / experiments only; -1 = the built-in default
-static long long g_opt_stream_serial = -1, g_opt_stream_blocks = -1, g_opt_stream_chunk_tiles = -1, g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1;
+static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1;
 extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     if (!key) return fail(IRIS_ERR_ARG, "iris_debug_set: null key");
     const std::string k(key);
     if (k == "bvh_max_leaf") g_opt_bvh_max_leaf = value;
     else if (k == "bvh_tri_cost_x100") g_opt_bvh_tri_cost_x100 = value;
-    else if (k == "stream_serial") g_opt_stream_serial = value;
-    else if (k == "stream_blocks") g_opt_stream_blocks = value;
-    else if (k == "stream_chunk_tiles") g_opt_stream_chunk_tiles = value;
     else if (k == "phase_min") g_opt_phase_min = value;
     else if (k == "tile_target_rays") g_opt_tile_target_rays = value;
     else if (k == "tiles_per_block") g_opt_tiles_per_block = value;
@@ -742,48 +738,6 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
-// ---- streamed view bake (iris_stream.h): tiles of all lobes in chunks of <= kStreamChunkRays ray slots
-static int stream_grid_blocks() { return num_cus() * (g_opt_stream_blocks > 0 ? (int)g_opt_stream_blocks : IRIS_STREAM_BLOCKS); }
-static long long stream_chunk_tiles(long long tiles) {
-    // >= 4 chunks where the view is large enough to pipeline, at most kStreamChunkRays slots per buffer set
-    if (g_opt_stream_chunk_tiles > 0) return std::min<long long>(std::max<long long>(tiles, 1), std::min<long long>(g_opt_stream_chunk_tiles, kStreamChunkRays / kTileRays));
-    return std::min<long long>(std::max<long long>((tiles + 3) / 4, std::min<long long>(tiles, 256)), kStreamChunkRays / kTileRays);
-}
-// side streams + events of the two-deep chunk pipeline (per device, created on first use; one view bake at a time per device)
-struct StreamPipe { hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t start = nullptr, done[2] = {nullptr, nullptr}; };
-static StreamPipe* stream_pipe(int device) {
-    static StreamPipe pipes[16];
-    if (device < 0 || device >= 16) return nullptr;
-    StreamPipe& p = pipes[device];
-    if (!p.start) {
-        for (int q = 0; q < 2; ++q) {
-            if (hipStreamCreateWithFlags(&p.s[q], hipStreamNonBlocking) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&p.done[q], hipEventDisableTiming) != hipSuccess) return nullptr;
-        }
-        if (hipEventCreateWithFlags(&p.start, hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return &p;
-}
-static long long view_tiles(int64_t P, int n_lobes, const int32_t* spp, int* tile_px_out /*nullable, n_lobes*/) {
-    long long t = 0;
-    for (int l = 0; l < n_lobes; ++l) {
-        if (spp[l] < 1 || spp[l] > kTileRays) return -1;
-        const int tile_px = std::max(1, kTileRays / spp[l]);
-        if (tile_px_out) tile_px_out[l] = tile_px;
-        t += (P + tile_px - 1) / tile_px;
-    }
-    return t;
-}
-static uint64_t stream_ovf_bytes() { return (uint64_t)num_cus() * 8 * (kStackCapacity - IRIS_TILE_STACK) * kBlock * sizeof(uint32_t); }
-extern "C" IRIS_API uint64_t iris_bake_view_workspace_bytes(int64_t P, int n_lobes, const int32_t* spp) {
-    if (P < 0 || n_lobes < 1 || n_lobes > kMaxLobes || !spp) return 0;
-    const long long tiles = view_tiles(P, n_lobes, spp, nullptr);
-    if (tiles < 0) return 0;
-    const uint64_t chunk_tiles = (uint64_t)stream_chunk_tiles(std::max<long long>(tiles, 1));
-    // two buffer sets, each [256 B counters][rec 16 B][hit 16 B][gw 8 B] per ray slot of a chunk [4 B per tile][traversal-stack overflow slabs]
-    return 2 * (256 + chunk_tiles * kTileRays * (16 + 16 + 8) + ((chunk_tiles * 4 + 255) / 256) * 256 + stream_ovf_bytes());
-}
-
 // All lobes of a view in one launch (see bake_view_kernel).  roughness[l] < 0 selects the diffuse lobe.
 extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                               const float* wo, const int32_t* pix_id, int64_t P, int n_lobes, const float* roughness, const int32_t* spp,
@@ -796,10 +750,7 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
         return fail(IRIS_ERR_ARG, "iris_bake_view: the emitter tables were built for a mesh with a different number of triangles than the scene");
     if (P == 0) return IRIS_OK;
     const uint64_t need = iris_bake_workspace_bytes(P, 1, 1);
-    const uint64_t need_stream = iris_bake_view_workspace_bytes(P, n_lobes, spp);
-    const bool streamed = workspace && need_stream > 0 && workspace_bytes >= need_stream;
-    if (!streamed && (!workspace || workspace_bytes < need))
-        return fail(IRIS_ERR_ARG, "iris_bake_view: workspace of iris_bake_view_workspace_bytes() (or at least iris_bake_workspace_bytes()) bytes required");
+    if (!workspace || workspace_bytes < need) return fail(IRIS_ERR_ARG, "iris_bake_view: workspace of iris_bake_workspace_bytes() bytes required");
     ViewArgs v{};
     v.base.sc = sc->dev; v.base.em = em->dev; v.base.slf = slf->dev;
     v.base.pos = pos; v.base.nrm = nrm; v.base.wo = wo; v.base.pix_id = pix_id; v.base.P = P; v.base.seed = seed;
@@ -821,55 +772,6 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
         t += (P + tile_px - 1) / tile_px;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (streamed) {
-        // full tiles (the per-tile balancing of the tile kernel does not apply: segments are drawn by waves)
-        int tpx[kMaxLobes];
-        const long long tiles = view_tiles(P, n_lobes, spp, tpx);
-        long long tb = 0;
-        for (int l = 0; l < n_lobes; ++l) { v.lobe[l].tile_px = tpx[l]; v.lobe[l].tile_begin = tb; tb += (P + tpx[l] - 1) / tpx[l]; }
-        v.n_tiles = tiles;
-        const long long chunk_tiles = stream_chunk_tiles(tiles);
-        StreamPipe* pipe = stream_pipe(sc->device);
-        if (!pipe) return fail(IRIS_ERR_HIP, "iris_bake_view: cannot create the side streams of the chunk pipeline");
-        static bool lds_ok = false;
-        if (!lds_ok) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes));
-            lds_ok = true;
-        }
-        const uint64_t set_bytes = need_stream / 2;
-        StreamArgs A[2];
-        for (int q = 0; q < 2; ++q) {
-            A[q] = StreamArgs{};
-            A[q].v = v;
-            char* wp = (char*)workspace + (size_t)q * set_bytes;
-            A[q].seg_counter = (unsigned int*)wp; wp += 256;
-            A[q].rec = (float4*)wp; wp += (size_t)chunk_tiles * kTileRays * 16;
-            A[q].hit = (float4*)wp; wp += (size_t)chunk_tiles * kTileRays * 16;
-            A[q].gw = (float2*)wp; wp += (size_t)chunk_tiles * kTileRays * 8;
-            A[q].tile_p0 = (int32_t*)wp; wp += (((size_t)chunk_tiles * 4 + 255) / 256) * 256;
-            A[q].stack_ovf = (uint32_t*)wp;
-        }
-        const bool q8 = v.base.sc.layout == kLayoutQ8;
-        // fork: chunk k runs sample -> trace -> shade on side stream k & 1 with buffer set k & 1, so that chunk k's traversal (VALU-bound) has
-        // chunk k-1's shading and chunk k+1's sampling (HBM-bound) beside it; join: the caller's stream waits for both
-        HIP_TRY(hipEventRecord(pipe->start, st));
-        for (int q = 0; q < 2; ++q) HIP_TRY(hipStreamWaitEvent(pipe->s[q], pipe->start, 0));
-        int k = 0;
-        for (long long t0 = 0; t0 < tiles; t0 += chunk_tiles, ++k) {
-            const int q = k & 1;
-            hipStream_t ss = g_opt_stream_serial > 0 ? pipe->s[0] : pipe->s[q];
-            A[q].tile0 = t0; A[q].n_tiles = std::min<long long>(chunk_tiles, tiles - t0);
-            HIP_TRY(hipMemsetAsync(A[q].seg_counter, 0, 256, ss));
-            hipLaunchKernelGGL(stream_sample_kernel, dim3((unsigned)A[q].n_tiles), dim3(kBlock), kSampleLdsBytes, ss, A[q]);
-            const int grid = (int)std::min<long long>(stream_grid_blocks(), (A[q].n_tiles * (kTileRays / kSegRays) + 3) / 4);
-            if (q8) hipLaunchKernelGGL(stream_trace_kernel<kLayoutQ8>, dim3(grid), dim3(kBlock), 0, ss, A[q]);
-            else hipLaunchKernelGGL(stream_trace_kernel<kLayoutF32>, dim3(grid), dim3(kBlock), 0, ss, A[q]);
-            hipLaunchKernelGGL(stream_shade_kernel, dim3((unsigned)A[q].n_tiles), dim3(kBlock), 0, ss, A[q]);
-        }
-        for (int q = 0; q < 2; ++q) { HIP_TRY(hipEventRecord(pipe->done[q], pipe->s[q])); HIP_TRY(hipStreamWaitEvent(st, pipe->done[q], 0)); }
-        HIP_TRY(hipGetLastError());
-        return IRIS_OK;
-    }
     v.n_tiles = t;
     HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
     const int grid = (int)std::min<long long>(blocks, t);
