@@ -1,0 +1,68 @@
+"""Device-side tables follow the modules: SLFEmitter / VoxelSLF cache their handles keyed on the tensors' version counters,
+so in-place edits, load_state_dict through the parent module and optimiser steps are picked up without an explicit refresh(); the modules may
+live on the CPU (the reference loads them with map_location='cpu'); a mesh / emitter mismatch is an error, not an out-of-bounds read."""
+import numpy as np
+import pytest
+import torch
+
+from test_hip_parity import dev, room_setup, T  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_in_place_edits_and_load_state_dict_reach_the_device(dev, room_setup):
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    em = s["em"]
+    P = 512
+    pos, nrm = T(s["pos"][:P], dev), T(s["nrm"][:P], dev)
+    base = bs.bake_diffuse(s["sc"], em, pos, nrm, 64, seed=9)
+    saved = {k: v.clone() for k, v in em.state_dict().items()}
+    try:
+        with torch.no_grad():                       # in-place edit of both radiance tables, NO refresh()
+            em.radiance.mul_(2.0); em.slf.radiance.mul_(2.0)
+        assert torch.equal(bs.bake_diffuse(s["sc"], em, pos, nrm, 64, seed=9), base * 2.0)
+        sd = {k: v.clone() for k, v in saved.items()}
+        sd["radiance"] = saved["radiance"] * 4.0; sd["slf.radiance"] = saved["slf.radiance"] * 4.0
+        em.load_state_dict(sd)                      # goes through nn.Module._load_from_state_dict of the PARENT: copies into the child's buffers
+        assert torch.equal(bs.bake_diffuse(s["sc"], em, pos, nrm, 64, seed=9), base * 4.0)
+        lookup = em.slf(pos)["rgb"]                 # the unfused lookup sees the same rows
+        em.slf.radiance.mul_(0.5)
+        assert torch.equal(em.slf(pos)["rgb"], lookup * 0.5)
+    finally:
+        em.load_state_dict(saved)
+    assert torch.equal(bs.bake_diffuse(s["sc"], em, pos, nrm, 64, seed=9), base)
+
+
+def test_emitter_for_another_mesh_is_rejected(dev, room_setup, tmp_path):
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.path_tracing import Scene
+    s = room_setup
+    r = s["room"]
+    small = Scene(r["vertices"], r["faces"][:1000], device=dev)          # a different mesh: 1000 triangles
+    pos, nrm = T(s["pos"][:8], dev), T(s["nrm"][:8], dev)
+    with pytest.raises(L.IrisError, match="different number of triangles"):
+        bs.bake_diffuse(small, s["em"], pos, nrm, 16)
+    with pytest.raises(L.IrisError, match="different number of triangles"):
+        bs.bake_lobes(small, s["em"], pos, nrm, pos, [None], [16])
+
+
+def test_tiny_far_nodes_do_not_lose_rays(dev, oracle_mod):
+    """Unused child slots of a node reference a degenerate leaf, never the idle marker: a scene of micrometre triangles far from the ray
+    origins (node planes collapse onto one t in f32) still returns the brute-force closest hits."""
+    from iris_amd.utils.path_tracing import Scene, ray_intersect
+    rng = np.random.default_rng(5)
+    n = 3000
+    c = rng.random((n, 3)).astype(np.float32) * 1e-3 + np.float32(900.0)            # a 1 mm cloud at distance 900 from the origin
+    v = (c[:, None, :] + (rng.random((n, 3, 3)).astype(np.float32) - 0.5) * np.float32(2e-6)).reshape(-1, 3)
+    f = np.arange(n * 3, dtype=np.int32).reshape(n, 3)
+    o = np.zeros((4096, 3), np.float32)
+    d = (c[rng.integers(0, n, 4096)] + (rng.random((4096, 3)).astype(np.float32) - 0.5) * np.float32(1e-6)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sc = Scene(v, f, device=dev)
+    _, _, _, idx, valid = ray_intersect(sc, T(o, dev), T(d, dev))
+    osc = oracle_mod.Scene(v, f)
+    _, _, _, oidx, ovalid = osc.ray_intersect(o, d, brute=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
+    np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), ovalid.astype(bool))
