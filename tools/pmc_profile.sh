@@ -5,7 +5,7 @@
 # usage: [IRIS_HIP_LIB=...] tools/pmc_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---steps 3 --warmup 1 --views 1 --cpu-seconds 0 --no-roofline --no-extras}
+ARGS=${@:---steps 4 --warmup 1 --cpu-seconds 0 --no-roofline --no-extras}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
