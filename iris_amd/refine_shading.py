@@ -1,0 +1,182 @@
+"""The refine_shading stage (reference: refine_shading.py:99-177) on MI355X: the shading cache re-baked with multi-bounce indirect light
+through the current material estimate -- per view a deterministic first hit, then `path_tracing_det_diff` (diffuse, spp 128, indir_depth 5)
+and `path_tracing_det_spec` for the six roughness levels (spp 64), denoised and written to the same 13 EXR files the bake wrote.
+
+The integrators are the HIP stages of `iris_amd.utils.path_tracing` (parity: tests/test_refine.py against the reference's goldens).  The
+material network is the reference's `NGPBRDF` -- a tiny-cuda-nn hash grid, third party and absent here -- so the driver takes ANY
+`material_net(position) -> {'albedo','roughness','metallic'}` module: `refine_view(...)` as a library call, `--material pkg.module:factory`
+on the command line (the factory is called with the (voxel_min, voxel_max) pair `NGPBRDF` is constructed from, refine_shading.py:83-84, and
+`--ckpt` is handed to it when given).
+"""
+import importlib
+import math
+import os
+import time
+
+import torch
+
+from . import _lib as L
+from .bake_shading import N_ROUGHNESS, _write_atomic, output_files, roughness_levels
+from .utils.path_tracing import path_tracing_det_diff, path_tracing_det_spec, ray_intersect
+
+SPP_DIFFUSE = 128          # refine_shading.py:103
+SPP_SPECULAR = 64          # refine_shading.py:137
+INDIR_DEPTH = 5            # refine_shading.py:104
+BATCH_RAYS = 10240 * 128   # rays per integrator call: batch_size = 10240*128//spp pixels (refine_shading.py:107, :139)
+
+
+@torch.no_grad()
+def refine_view(scene, emitter, material_net, xs, ds, spp_diffuse=SPP_DIFFUSE, spp_specular=SPP_SPECULAR, indir_depth=INDIR_DEPTH, batch_rays=BATCH_RAYS,
+                denoiser=None, lobes=None, uniforms=None):
+    """One iteration of the reference's two per-view loops (refine_shading.py:109-127 and :144-174).
+    xs, ds: (N,3) pixel-centre rays of the view on the GPU.  Returns {'diffuse': (N,3), 'specular0': [6 x (N,3)], 'specular1': [...]}
+    (zeros at pixels whose primary ray misses).  denoiser: a utils.denoise.Denoiser for the full image; as in the reference EVERY map is
+    denoised here (the bake skips roughness level 0, refine_shading does not).  lobes: subset of {0, 1..6}.  uniforms: optional dict
+    lobe -> list of draw lists (one per batch) for parity runs."""
+    xs = L.require_gpu(xs, torch.float32, "xs").reshape(-1, 3)
+    ds = L.require_gpu(ds, torch.float32, "ds").reshape(-1, 3)
+    positions, normals, uvs, triangle_idxs, valid = ray_intersect(scene, xs, ds)
+    wi = ds
+    B, dev = positions.shape[0], positions.device
+    want = [l for l in range(N_ROUGHNESS + 1) if lobes is None or l in lobes]
+    levels = roughness_levels()
+    out = {"specular0": [], "specular1": [], "n_valid": int(valid.sum())}
+
+    def batches(spp):
+        bs = max(1, batch_rays // spp)
+        return [(b * bs, min((b + 1) * bs, B)) for b in range(math.ceil(B / bs))]
+
+    if 0 in want:
+        Ld = torch.zeros(B, 3, device=dev)
+        for k, (b0, b1) in enumerate(batches(spp_diffuse)):
+            u = None if uniforms is None else uniforms[0][k]
+            Ld[b0:b1] = path_tracing_det_diff(scene, emitter, material_net, positions[b0:b1], wi[b0:b1], normals[b0:b1], uvs[b0:b1], triangle_idxs[b0:b1],
+                                              spp_diffuse, indir_depth, uniforms=u)
+        if torch.isnan(Ld).any():
+            raise L.IrisError("refine_view: NaN in the diffuse shading")           # assert L.isnan().any() == False   (:124)
+        out["diffuse"] = Ld
+    for l in want:
+        if l == 0:
+            continue
+        L0 = torch.zeros(B, 3, device=dev); L1 = torch.zeros(B, 3, device=dev)
+        for k, (b0, b1) in enumerate(batches(spp_specular)):
+            u = None if uniforms is None else uniforms[l][k]
+            a, b = path_tracing_det_spec(scene, emitter, material_net, levels[l - 1], positions[b0:b1], wi[b0:b1], normals[b0:b1], uvs[b0:b1],
+                                         triangle_idxs[b0:b1], spp_specular, indir_depth, uniforms=u)
+            L0[b0:b1] = a; L1[b0:b1] = b
+        if torch.isnan(L0).any() or torch.isnan(L1).any():
+            raise L.IrisError("refine_view: NaN in the specular shading")
+        out["specular0"].append(L0); out["specular1"].append(L1)
+    if denoiser is not None:
+        if B != denoiser.H * denoiser.W:
+            raise L.IrisError("refine_view: denoising needs the whole image in image order")
+        denoiser.set_guides(normals, positions, valid)
+        names = ([("diffuse", None)] if "diffuse" in out else []) + [(k, i) for i in range(len(out["specular0"])) for k in ("specular0", "specular1")]
+        den = denoiser.denoise_maps([out[k] if i is None else out[k][i] for k, i in names])
+        for (k, i), d in zip(names, den):
+            if i is None:
+                out[k] = d.reshape(B, 3)
+            else:
+                out[k][i] = d.reshape(B, 3)
+    return out
+
+
+def _load_material(spec, slf_path, ckpt):
+    mod, _, attr = spec.partition(":")
+    factory = getattr(importlib.import_module(mod), attr or "material")
+    mask = torch.load(slf_path, map_location="cpu")
+    try:
+        return factory(mask["voxel_min"], mask["voxel_max"], ckpt) if ckpt else factory(mask["voxel_min"], mask["voxel_max"])
+    except TypeError:
+        return factory()
+
+
+def main(argv=None):
+    """python -m iris_amd.refine_shading --scene S --slf_path vslf.npz --emitter_path emitter.pth --output OUT --dataset synthetic|real|generic
+       --material pkg.module:factory [--ckpt last.ckpt]          (the reference's flags; --material replaces the hard-wired NGPBRDF)"""
+    import argparse
+    from .model.emitter import SLFEmitter
+    from .utils import cameras, exr
+    from .utils.path_tracing import load_scene
+    parser = argparse.ArgumentParser(description=main.__doc__)
+    parser.add_argument("--dataset_root", type=str, help="dataset root")
+    parser.add_argument("--scene", type=str, required=True, help="dataset folder")
+    parser.add_argument("--slf_path", type=str, required=True)
+    parser.add_argument("--emitter_path", type=str, required=True)
+    parser.add_argument("--output", type=str, required=True, help="last shading folder")
+    parser.add_argument("--ckpt", type=str, default=None, help="checkpoint path (handed to the material factory)")
+    parser.add_argument("--dataset", type=str, required=True, help="dataset type: synthetic | real | scannetpp | generic")
+    parser.add_argument("--ldr_img_dir", type=str, default=None)
+    parser.add_argument("--res_scale", type=float, default=1.0)
+    # additions (defaults reproduce the reference)
+    parser.add_argument("--material", type=str, required=True, help="pkg.module:factory returning material_net(position) -> {'albedo','roughness','metallic'}")
+    parser.add_argument("--cameras", type=str, default=None, help="generic camera JSON (required for scannetpp: COLMAP I/O is out of scope)")
+    parser.add_argument("--img_hw", type=int, nargs=2, default=None)
+    parser.add_argument("--spp_diffuse", type=int, default=SPP_DIFFUSE)
+    parser.add_argument("--spp_specular", type=int, default=SPP_SPECULAR)
+    parser.add_argument("--indir_depth", type=int, default=INDIR_DEPTH)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--compression", type=str, default="zip", choices=["none", "zips", "zip"])
+    parser.add_argument("--overwrite", action="store_true")
+    parser.add_argument("--denoise", type=str, default="atrous", choices=["atrous", "none"])
+    args = parser.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise L.IrisError("refine_shading needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if args.dataset in ("synthetic", "real"):
+        mesh_path = os.path.join(args.scene, "scene.obj")
+    elif args.dataset == "scannetpp":
+        mesh_path = os.path.join(args.dataset_root, "data", args.scene, "scans", "scene.ply")
+    else:
+        mesh_path = os.path.join(args.scene, "scene.obj") if os.path.exists(os.path.join(args.scene, "scene.obj")) else os.path.join(args.scene, "scene.ply")
+    assert os.path.exists(mesh_path), "mesh not found: " + mesh_path
+    scene = load_scene(mesh_path, device=device)
+    hw = tuple(args.img_hw) if args.img_hw else None
+    if args.cameras:
+        img_hw, views = cameras.load_generic(args.cameras, args.res_scale)
+    elif args.dataset == "synthetic":
+        img_hw, views = cameras.load_synthetic(args.scene, args.res_scale, hw)
+    elif args.dataset == "real":
+        img_hw, views = cameras.load_real(args.scene, args.res_scale, hw)
+    else:
+        raise L.IrisError("--dataset scannetpp needs --cameras cameras.json (COLMAP / nerfstudio parsing is dataset I/O outside this path)")
+    emitter = SLFEmitter(args.emitter_path, args.slf_path)
+    material_net = _load_material(args.material, args.slf_path, args.ckpt)
+    if isinstance(material_net, torch.nn.Module):
+        material_net.to(device)
+        for p in material_net.parameters():
+            p.requires_grad = False
+    os.makedirs(os.path.join(args.output, "diffuse"), exist_ok=True)
+    os.makedirs(os.path.join(args.output, "specular"), exist_ok=True)
+    denoiser = None
+    if args.denoise == "atrous":
+        from .utils.denoise import Denoiser
+        denoiser = Denoiser(img_hw[::-1], device)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=min(13, os.cpu_count() or 4))
+    pending, start_time = [], time.time()
+    for im_id in range(rank, len(views), world):
+        files = output_files(args.output, im_id)
+        if not args.overwrite and all(os.path.exists(f) for f in files):
+            continue
+        torch.manual_seed(args.seed * 1000003 + im_id); torch.cuda.manual_seed(args.seed * 1000003 + im_id)     # the integrators draw with torch.rand
+        xs, ds = cameras.view_rays(views[im_id], img_hw, device)
+        out = refine_view(scene, emitter, material_net, xs, ds, args.spp_diffuse, args.spp_specular, args.indir_depth, denoiser=denoiser)
+        maps = torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3).cpu().numpy()
+        while len(pending) >= 2 * 13:
+            pending.pop(0).result()
+        for f, m in zip(files, maps):
+            pending.append(pool.submit(_write_atomic, exr, f, m, args.compression))
+    for p in pending:
+        p.result()
+    pool.shutdown()
+    torch.cuda.synchronize()
+    print("[refine_shading] rank {}: {:.2f} s".format(rank, time.time() - start_time))
+
+
+if __name__ == "__main__":
+    main()

@@ -19,3 +19,8 @@ class StubMaterial(torch.nn.Module):
 def stub_material_np(position):
     out = StubMaterial()(torch.from_numpy(np.ascontiguousarray(position, dtype=np.float32)))
     return {k: v.numpy() for k, v in out.items()}
+
+
+def material(voxel_min=None, voxel_max=None, ckpt=None):
+    """factory with the signature `python -m iris_amd.refine_shading --material stub_material:material` expects (NGPBRDF(voxel_min, voxel_max))"""
+    return StubMaterial()

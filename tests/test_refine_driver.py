@@ -1,0 +1,86 @@
+"""The refine_shading driver (reference: refine_shading.py:99-177): per view the deterministic first hit, path_tracing_det_diff at spp 128 /
+indir_depth 5, path_tracing_det_spec for the six roughness levels at spp 64, every map denoised, the bake's 13 file names.  The integrators
+themselves are pinned to the reference's goldens in tests/test_refine.py; here the loop around them."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from stub_material import StubMaterial
+from test_pt_single import _gpu_setup
+
+pytestmark = pytest.mark.gpu
+
+
+def test_refine_view_is_the_reference_loop(tmp_path):
+    from iris_amd import refine_shading as rs
+    from iris_amd.utils.dataset import real_ldr
+    from iris_amd.utils.path_tracing import path_tracing_det_diff, path_tracing_det_spec, ray_intersect
+    dev = torch.device("cuda:0")
+    g, _, sc, em = _gpu_setup(tmp_path, dev)
+    H, W = int(g["H"]), int(g["W"])
+    xs, ds = real_ldr.to_world(real_ldr.get_direction(g["K"], (H, W)), g["c2w"], False, device=dev)
+    mat = StubMaterial()
+    spp_d, spp_s, depth = 8, 4, 3
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    out = rs.refine_view(sc, em, mat, xs, ds, spp_d, spp_s, depth, batch_rays=300 * spp_d)       # several ragged batches per lobe
+    # the loop of refine_shading.py:109-127 / :144-174 written out, same draw order
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    pos, nrm, uv, tri, valid = ray_intersect(sc, xs, ds)
+    B = pos.shape[0]
+    Ld = torch.zeros(B, 3, device=dev)
+    bs = 300 * spp_d // spp_d
+    for b0 in range(0, B, bs):
+        b1 = min(b0 + bs, B)
+        Ld[b0:b1] = path_tracing_det_diff(sc, em, mat, pos[b0:b1], ds[b0:b1], nrm[b0:b1], uv[b0:b1], tri[b0:b1], spp_d, depth)
+    assert torch.equal(out["diffuse"], Ld)
+    bs = 300 * spp_d // spp_s
+    for r_idx, rough in enumerate(torch.linspace(0.02, 1.0, 6)):
+        L0 = torch.zeros(B, 3, device=dev); L1 = torch.zeros(B, 3, device=dev)
+        for b0 in range(0, B, bs):
+            b1 = min(b0 + bs, B)
+            L0[b0:b1], L1[b0:b1] = path_tracing_det_spec(sc, em, mat, rough, pos[b0:b1], ds[b0:b1], nrm[b0:b1], uv[b0:b1], tri[b0:b1], spp_s, depth)
+        assert torch.equal(out["specular0"][r_idx], L0) and torch.equal(out["specular1"][r_idx], L1)
+    assert out["n_valid"] == int(valid.sum()) and torch.isfinite(Ld).all() and float(Ld.sum()) > 0
+    assert float(out["diffuse"][~valid].abs().sum()) == 0.0                                  # misses stay zero
+
+
+def test_refine_cli_writes_the_bake_file_set(tmp_path):
+    from iris_amd import bake_shading as bs, refine_shading as rs
+    from iris_amd.utils import exr
+    from iris_amd.model.slf import VoxelSLF
+    g = golden("bake_box.npz")
+    p = golden("pt_single.npz")
+    scene_dir = tmp_path / "scene"; scene_dir.mkdir()
+    with open(scene_dir / "scene.obj", "w") as fh:
+        for v in g["verts"]:
+            fh.write("v {} {} {}\n".format(*v))
+        for f in g["faces"]:
+            fh.write("f {} {} {}\n".format(*(f + 1)))
+    H, W = 12, 16
+    K = np.array([[0.8 * W, 0, W / 2.0], [0, 0.8 * W, H / 2.0], [0, 0, 1]], np.float32)
+    cams = {"img_hw": [H, W], "views": [{"K": K.tolist(), "c2w": g["c2w"].tolist()}, {"K": K.tolist(), "c2w": g["c2w"].tolist()}]}
+    json.dump(cams, open(tmp_path / "cams.json", "w"))
+    slf = VoxelSLF(torch.from_numpy(g["slf_mask"]), float(g["voxel_min"]), float(g["voxel_max"]))
+    slf.radiance[:] = torch.from_numpy(g["slf_radiance"])
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    torch.save({"is_emitter": torch.from_numpy(g["is_emitter"]), "emitter_vertices": torch.from_numpy(p["emitter_vertices"]), "emitter_area": torch.from_numpy(g["emitter_area"]),
+                "emitter_normal": torch.zeros(int(g["is_emitter"].sum()), 3), "emitter_radiance": torch.from_numpy(g["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(g["slf_mask"]), "voxel_min": float(g["voxel_min"]), "voxel_max": float(g["voxel_max"]), "weight": slf.state_dict()}, sp)
+    out = str(tmp_path / "out")
+    argv = ["--scene", str(scene_dir), "--slf_path", sp, "--emitter_path", ep, "--output", out, "--dataset", "generic", "--cameras", str(tmp_path / "cams.json"),
+            "--material", "stub_material:material", "--spp_diffuse", "8", "--spp_specular", "4", "--indir_depth", "2", "--seed", "2"]
+    rs.main(argv)
+    for im_id in (0, 1):
+        files = bs.output_files(out, im_id)
+        assert len(files) == 13 and all(os.path.exists(f) for f in files)
+        img = exr.read_exr(files[0])
+        assert img.shape == (H, W, 3) and np.isfinite(img).all() and float(img.sum()) > 0
+    a, b = exr.read_exr(bs.output_files(out, 0)[0]), exr.read_exr(bs.output_files(out, 1)[0])
+    assert not np.array_equal(a, b)                        # same camera, per-view seeds: independent noise
+    mt = os.path.getmtime(bs.output_files(out, 0)[0])
+    rs.main(argv)                                          # resume: nothing is re-rendered
+    assert os.path.getmtime(bs.output_files(out, 0)[0]) == mt
