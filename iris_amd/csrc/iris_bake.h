@@ -13,10 +13,6 @@
 
 namespace iris {
 
-#ifdef IRIS_LDS_PAD_TEST
-__device__ int g_pad_idx;
-__device__ __forceinline__ int a_pad_idx() { return g_pad_idx; }
-#endif
 struct BakeArgs {
     SceneDev sc; EmitDev em; SlfDev slf;
     const float* pos; const float* nrm; const float* wo;
@@ -183,9 +179,6 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU): 7 x 20 488 B of LDS, 72 VGPRs.
 #define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s
 #endif
-#ifndef IRIS_HANDOVER            // hand the last rays of a tile over between its waves (iris_tile.h TileHandOver, +1828 B of LDS)
-#define IRIS_HANDOVER 1
-#endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
 #define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
 #endif
@@ -201,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 //   once per tile and was measured 9 % slower per fence pair).
 template <bool SPEC, bool COUNT, int LAYOUT, int TILE_STACK>
 __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, float4* res, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk,
-                                          uint32_t* ovf, TileHandOver* hand, TraceStats& ts, uint32_t& n_rays) {
+                                          uint32_t* ovf, TraceStats& ts, uint32_t& n_rays) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int spp = a.spp;
     float2* res_g = reinterpret_cast<float2*>(res + kTileRays);   // GGX weights (g1, g0): second array of the slab
@@ -214,8 +207,8 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     const int nr = np * spp;
 
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
-    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true, IRIS_HANDOVER != 0>(
-        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, hand, ts,
+    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
+        a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
         [&](int r) -> uint32_t {
             const int pl = r / spp, s = r - pl * spp;
             const int64_t p = p0 + pl;
@@ -316,10 +309,6 @@ __global__ __launch_bounds__(kBlock, COUNT ? 4 : IRIS_TILE_WAVES) void bake_tile
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
-    __shared__ TileHandOver s_hand;
-#ifdef IRIS_LDS_PAD_TEST
-    __shared__ uint32_t s_pad[IRIS_LDS_PAD_TEST]; if (threadIdx.x == 1000) s_pad[a_pad_idx()] = 1;
-#endif
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
     constexpr int NC = SPEC ? 2 : 1;
@@ -335,7 +324,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? 4 : IRIS_TILE_WAVES) void bake_tile
         __syncthreads();
         const int64_t tile = s_tile;
         if (tile >= n_tiles) break;
-        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, IRIS_HANDOVER ? &s_hand : nullptr, ts, n_rays);
+        tile_body<SPEC, COUNT, LAYOUT, kTileStack>(a, tile, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
     }
     flush_stats<COUNT>(a, ts, n_rays);
 }
@@ -361,10 +350,6 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
     __shared__ uint16_t s_sorted[kTileRays];
     __shared__ uint32_t s_stack[kTileStack * kBlock];
     __shared__ int s_tile, s_chunk;
-    __shared__ TileHandOver s_hand;
-#ifdef IRIS_LDS_PAD_TEST
-    __shared__ uint32_t s_pad[IRIS_LDS_PAD_TEST]; if (threadIdx.x == 1000) s_pad[a_pad_idx()] = 1;
-#endif
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
     float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
@@ -382,8 +367,8 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
         a.spp = v.lobe[l].spp; a.rough = v.lobe[l].rough; a.stream_id = v.lobe[l].stream_id; a.tile_px = v.lobe[l].tile_px;
         a.out0 = v.lobe[l].out0; a.out1 = v.lobe[l].out1; a.u2 = nullptr; a.tri_next = nullptr; a.src_next = nullptr;
         TraceStats ts; uint32_t n_rays = 0;   // unused (COUNT = false)
-        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, IRIS_HANDOVER ? &s_hand : nullptr, ts, n_rays);
-        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, IRIS_HANDOVER ? &s_hand : nullptr, ts, n_rays);
+        if (v.lobe[l].spec) tile_body<true, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
+        else tile_body<false, false, LAYOUT, kTileStack>(a, gt - v.lobe[l].tile_begin, res, s_sorted, s_stack, &s_chunk, ovf, ts, n_rays);
     }
 }
 

@@ -248,8 +248,8 @@ __global__ __launch_bounds__(kBlock, IRIS_PT_WAVES) void pt_tiled_kernel(PtArgs 
         const int nr = (int)min((int64_t)tile_rays, a.N - i0);
         float* dir = NEE ? a.coef1 : a.wi_out;       // where the direction is parked
         float* rec = NEE ? a.coef1 : a.pos_next;     // where (u, v[, slot]) is parked
-        tile_sort_trace<LAYOUT, false, kPtTileCap, kPtTileStack, false, false>(
-            a.sc, nr, s_sorted, s_stack, &s_chunk, nullptr, nullptr, ts,
+        tile_sort_trace<LAYOUT, false, kPtTileCap, kPtTileStack, false>(
+            a.sc, nr, s_sorted, s_stack, &s_chunk, nullptr, ts,
             [&](int r) -> uint32_t {
                 const int64_t i = i0 + r;
                 f3 wi;

@@ -258,34 +258,9 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 #define IRIS_REFILL_MIN 48
 #endif
 constexpr int kRefillMin = IRIS_REFILL_MIN;
-//   tail (optional)      : hand-over of the last rays between the waves that share a ray list (tile_sort_trace's TileHandOver).  Once the
-//                          list is exhausted a wave that is down to <= kTailMax unfinished rays may PARK them -- best hit, current
-//                          reference and stack depth go to LDS, the stack contents stay in the parking lane's column -- and leave; a
-//                          wave that is still running ADOPTS parked rays into its idle lanes (tail.adopt() claims them and issues the
-//                          ray loads like fetch(); tail.resume() restores the traversal one round later) and continues them where they
-//                          stopped, so the tile's last long rays end up sharing one wave instead of keeping four waves alive at a few
-//                          % lane utilisation.  Per-ray results do not change: the same node / leaf steps run, on another lane.
-//                          tail.park() refuses when the caller is the last wave running; tail.leave() refuses while parked rays are
-//                          unclaimed and the caller is the last one who could take them.
-struct NoTail {
-    static constexpr bool kEnabled = false;
-    template <class S> __device__ __forceinline__ void resume(RayState&, S&) {}
-    __device__ __forceinline__ bool available() { return false; }
-    __device__ __forceinline__ bool adopt(f3&, f3&) { return false; }
-    template <class S> __device__ __forceinline__ bool park(const RayState&, const S&) { return false; }
-    __device__ __forceinline__ bool leave() { return true; }
-};
-#ifndef IRIS_TAIL_MAX
-#define IRIS_TAIL_MAX 16
-#endif
-constexpr int kTailMax = IRIS_TAIL_MAX;       // park when at most this many rays of the wave are unfinished
-#ifndef IRIS_ADOPT_MIN
-#define IRIS_ADOPT_MIN 16
-#endif
-constexpr int kAdoptMin = IRIS_ADOPT_MIN;   // adopt when at least this many lanes are idle
-template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire, class Tail = NoTail>
+template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire>
 __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
-                                             Retire retire, Tail tail = Tail()) {
+                                             Retire retire) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(r, r.o, r.d);
@@ -303,7 +278,6 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 prepare(r.o, r.d);
                 ray_begin(r, r.o, r.d);
                 st.sp = 0;
-                if (Tail::kEnabled) tail.resume(r, st);
                 if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
             }
             pend = 0;
@@ -320,25 +294,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             pend = __ballot(got);
             if (pend == 0) more = false;
         }
-        if (Tail::kEnabled && !more && pend == 0) {
-            if (n_idle >= kAdoptMin && tail.available()) {          // take over rays other waves of the tile have parked
-                bool got = false;
-                if (idle) {
-                    if (live) retire(r.h);
-                    live = got = tail.adopt(r.o, r.d);
-                }
-                pend = __ballot(got);
-            }
-            const int n_act = __popcll(__ballot(r.cur != kEmptyRef));
-            if (n_act == 0) {
-                if (pend == 0 && tail.leave()) break;
-                continue;
-            }
-            if (pend == 0 && n_act <= kTailMax && tail.park(r, st)) {
-                if (r.cur != kEmptyRef) live = false;                 // handed over: another wave retires it
-                break;
-            }
-        } else if (__ballot(r.cur != kEmptyRef) == 0) {
+        if (__ballot(r.cur != kEmptyRef) == 0) {
             if (pend == 0 && !more) break;
             continue;
         }
