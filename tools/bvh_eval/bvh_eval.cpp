@@ -73,6 +73,20 @@ int main(int argc, char** argv) {
     for (int64_t i = 0; i < nf; ++i) { V3 c = cross(sub(vert(i, 1), vert(i, 0)), sub(vert(i, 2), vert(i, 0))); acc += 0.5 * std::sqrt(dot(c, c)); cdf[i] = acc; }
     long long tot_nodes = 0, tot_tris = 0, hits = 0, max_sp = 0;
     std::vector<uint32_t> stack(256);
+    std::vector<float> dstack(256);
+    const char* cm = getenv("BVH_EVAL_CULL");   // unset: as the kernels (no distances on the stack); "exact": skip popped entries whose entry distance exceeds the best hit; "<m>": the same through a code of exponent + m mantissa bits
+    const int cull_bits = !cm ? -2 : (!strcmp(cm, "exact") ? -1 : atoi(cm));
+    long long skipped_nodes = 0, skipped_leaves = 0;
+    auto code = [&](float t) -> uint32_t { uint32_t b; memcpy(&b, &t, 4); return b >> (23 - cull_bits); };
+    auto pop = [&](int& sp, float best) -> uint32_t {
+        while (sp) {
+            --sp;
+            const bool skip = cull_bits == -2 ? false : cull_bits == -1 ? dstack[sp] > best : code(dstack[sp]) > code(best);
+            if (!skip) return stack[sp];
+            if (stack[sp] & 0x80000000u) ++skipped_leaves; else ++skipped_nodes;
+        }
+        return 0xffffffffu;
+    };
     for (int r = 0; r < n_rays; ++r) {
         const int64_t fi = std::lower_bound(cdf.begin(), cdf.end(), U(rng) * acc) - cdf.begin();
         float a = U(rng), b = U(rng);
@@ -105,8 +119,8 @@ int main(int argc, char** argv) {
                     V3 tv = sub(o, q0); float uu = dot(tv, pv) * inv; V3 qv = cross(tv, f1); float vv = dot(d, qv) * inv; float tt = dot(f2, qv) * inv;
                     if (uu >= 0 && vv >= 0 && uu + vv <= 1 && tt >= 0 && tt < best) best = tt;
                 }
-                if (!sp) break;
-                cur = stack[--sp];
+                cur = pop(sp, best);
+                if (cur == 0xffffffffu) break;
                 continue;
             }
             ++tot_nodes;
@@ -122,8 +136,8 @@ int main(int argc, char** argv) {
                 if (tn <= tf) { key[m] = tn; ref[m] = w.child[s] >= 0 ? (uint32_t)w.child[s] : (0x80000000u | (uint32_t)w.leaf_start[s] << 3 | (uint32_t)w.leaf_count[s]); ++m; }
             }
             for (int i = 1; i < m; ++i) for (int j = i; j > 0 && key[j] < key[j - 1]; --j) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
-            if (m == 0) { if (!sp) break; cur = stack[--sp]; continue; }
-            for (int i = m - 1; i >= 1; --i) stack[sp++] = ref[i];
+            if (m == 0) { cur = pop(sp, best); if (cur == 0xffffffffu) break; continue; }
+            for (int i = m - 1; i >= 1; --i) { dstack[sp] = key[i]; stack[sp++] = ref[i]; }
             max_sp = std::max<long long>(max_sp, sp);
             cur = ref[0];
         }
@@ -132,8 +146,8 @@ int main(int argc, char** argv) {
     size_t leaves = 0, leaf_tris = 0, children = 0;
     for (const auto& w : bvh.nodes) for (int s = 0; s < w.n; ++s) { ++children; if (w.child[s] < 0) { ++leaves; leaf_tris += w.leaf_count[s]; } }
     printf("{\"triangles\": %lld, \"nodes\": %zu, \"depth\": %d, \"sah\": %.3f, \"build_s\": %.2f, \"children_per_node\": %.3f, \"tris_per_leaf\": %.3f, "
-           "\"rays\": %d, \"hit_frac\": %.4f, \"nodes_per_ray\": %.3f, \"tris_per_ray\": %.3f, \"max_stack\": %lld}\n",
+           "\"rays\": %d, \"hit_frac\": %.4f, \"nodes_per_ray\": %.3f, \"tris_per_ray\": %.3f, \"max_stack\": %lld, \"cull\": \"%s\", \"skipped_nodes_per_ray\": %.3f, \"skipped_leaves_per_ray\": %.3f}\n",
            (long long)nf, nn, bvh.depth, bvh.sah_cost, build_s, (double)children / nn, (double)leaf_tris / leaves, n_rays, (double)hits / n_rays,
-           (double)tot_nodes / n_rays, (double)tot_tris / n_rays, max_sp);
+           (double)tot_nodes / n_rays, (double)tot_tris / n_rays, max_sp, cm ? cm : "none", (double)skipped_nodes / n_rays, (double)skipped_leaves / n_rays);
     return 0;
 }
