@@ -52,7 +52,7 @@ typedef struct {
     int32_t node_bytes;    /* bytes per node as stored in HBM */
     int32_t tri_bytes;     /* stride of a leaf-triangle record (64: p0, e1, e2, id, p1, p2)  */
     int32_t depth;         /* wide-tree depth */
-    int32_t reserved_;     /* 0 */
+    int32_t n_leaf_records;/* leaf-triangle records: n_triangles + the extra references of split long triangles */
     float   sah_cost;      /* SAH cost of the binary tree the wide tree was collapsed from */
     float   build_seconds;
 } iris_scene_info;

@@ -17,7 +17,7 @@ class IrisError(RuntimeError):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_vertices", C.c_int64), ("n_triangles", C.c_int64), ("layout", C.c_int32), ("n_nodes", C.c_int32),
-                ("node_bytes", C.c_int32), ("tri_bytes", C.c_int32), ("depth", C.c_int32), ("reserved_", C.c_int32),
+                ("node_bytes", C.c_int32), ("tri_bytes", C.c_int32), ("depth", C.c_int32), ("n_leaf_records", C.c_int32),
                 ("sah_cost", C.c_float), ("build_seconds", C.c_float)]
 
 

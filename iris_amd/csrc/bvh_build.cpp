@@ -117,6 +117,45 @@ struct Builder {
     }
 };
 
+// Bounds of (triangle  intersected with  box), Sutherland-Hodgman in double, rounded outward to float.  false: empty.
+bool clipped_bounds(const float* v0, const float* v1, const float* v2, const Box& box, Box& out) {
+    double poly[16][3], tmp[16][3];
+    int n = 3;
+    for (int k = 0; k < 3; ++k) { poly[0][k] = v0[k]; poly[1][k] = v1[k]; poly[2][k] = v2[k]; }
+    for (int ax = 0; ax < 3 && n > 0; ++ax) {
+        for (int side = 0; side < 2 && n > 0; ++side) {
+            const double plane = side == 0 ? (double)box.lo[ax] : (double)box.hi[ax], sgn = side == 0 ? 1.0 : -1.0;
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const double* a = poly[i]; const double* b = poly[(i + 1) % n];
+                const double da = sgn * (a[ax] - plane), db = sgn * (b[ax] - plane);
+                if (da >= 0.0) { for (int k = 0; k < 3; ++k) tmp[m][k] = a[k]; ++m; }
+                if ((da > 0.0 && db < 0.0) || (da < 0.0 && db > 0.0)) {
+                    const double t = da / (da - db);
+                    for (int k = 0; k < 3; ++k) tmp[m][k] = a[k] + t * (b[k] - a[k]);
+                    tmp[m][ax] = plane;
+                    ++m;
+                }
+            }
+            n = m;
+            for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
+        }
+    }
+    if (n == 0) return false;
+    out.reset();
+    for (int i = 0; i < n; ++i) {
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = (float)poly[i][k]; if ((double)lo[k] > poly[i][k]) lo[k] = std::nextafter(lo[k], -kInf);
+            hi[k] = (float)poly[i][k]; if ((double)hi[k] < poly[i][k]) hi[k] = std::nextafter(hi[k], kInf);
+        }
+        out.grow(lo, hi);
+    }
+    for (int k = 0; k < 3; ++k) { out.lo[k] = std::max(out.lo[k], box.lo[k]); out.hi[k] = std::min(out.hi[k], box.hi[k]); }   // (never outside the box it was cut from)
+    for (int k = 0; k < 3; ++k) if (out.lo[k] > out.hi[k]) return false;
+    return true;
+}
+
 float sah_of(const Node2* nodes, int32_t i, float root_area) {
     const Node2& n = nodes[i];
     float a = n.b.area() / root_area;
@@ -127,7 +166,7 @@ float sah_of(const Node2* nodes, int32_t i, float root_area) {
 }  // namespace
 
 WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces, int64_t nf, int width, int leaf_tris,
-                       float pad_rel, float tri_cost) {
+                       float pad_rel, float tri_cost, float presplit) {
     leaf_tris = std::min(7, std::max(1, leaf_tris));
     WideBvh out;
     out.width = width;
@@ -158,10 +197,60 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
     const float pad = pad_rel * ext + 1e-30f;
     out.pad = pad;
 
-    std::vector<Node2> nodes((size_t)(2 * nf));
+    // ---- early split clipping: a triangle much longer than the typical one (decimated walls and floors next to fine detail) is
+    // referenced through several boxes, each the bounds of the triangle clipped to a piece of its box, so that it does not force one
+    // large leaf box across everything beside it.  A reference whose longest side exceeds presplit x (median longest side) is cut at the
+    // middle of that side, largest first, until none is left or the references have grown by a quarter.  The leaf records of a split
+    // triangle are copies with the same index: the closest hit is a minimum over (t, index), so duplicates cannot change it.
+    std::vector<int32_t> ref_tri;              // reference -> triangle (empty: identity)
+    if (presplit > 0.f && nf >= 2) {
+        std::vector<float> side((size_t)nf);
+        auto longest = [](const Box& b, int& ax) { float m = -1.f; ax = 0; for (int k = 0; k < 3; ++k) if (b.hi[k] - b.lo[k] > m) { m = b.hi[k] - b.lo[k]; ax = k; } return m; };
+        int ax;
+        for (int64_t f = 0; f < nf; ++f) side[(size_t)f] = longest(tri[(size_t)f].b, ax);
+        std::vector<float> sorted(side);
+        std::nth_element(sorted.begin(), sorted.begin() + nf / 2, sorted.end());
+        const float limit = presplit * sorted[(size_t)(nf / 2)];
+        if (limit > 0.f) {
+            struct Cand { float side; int32_t ref; bool operator<(const Cand& o) const { return side < o.side || (side == o.side && ref > o.ref); } };
+            std::vector<Cand> heap;
+            for (int64_t f = 0; f < nf; ++f) if (side[(size_t)f] > limit) heap.push_back({side[(size_t)f], (int32_t)f});
+            if (!heap.empty()) {
+                std::make_heap(heap.begin(), heap.end());
+                ref_tri.resize((size_t)nf);
+                for (int64_t f = 0; f < nf; ++f) ref_tri[(size_t)f] = (int32_t)f;
+                const size_t max_refs = (size_t)nf + std::max<size_t>((size_t)nf / 4, 1024);
+                while (!heap.empty() && tri.size() < max_refs) {
+                    std::pop_heap(heap.begin(), heap.end());
+                    const Cand c = heap.back(); heap.pop_back();
+                    const Box b = tri[(size_t)c.ref].b;
+                    longest(b, ax);
+                    const float mid = 0.5f * (b.lo[ax] + b.hi[ax]);
+                    if (!(mid > b.lo[ax] && mid < b.hi[ax])) continue;
+                    Box lb = b, rb = b; lb.hi[ax] = mid; rb.lo[ax] = mid;
+                    const int32_t f = ref_tri[(size_t)c.ref];
+                    const float *v0 = verts + (int64_t)faces[(int64_t)f * 3] * 3, *v1 = verts + (int64_t)faces[(int64_t)f * 3 + 1] * 3, *v2 = verts + (int64_t)faces[(int64_t)f * 3 + 2] * 3;
+                    Box lc, rc;
+                    if (!clipped_bounds(v0, v1, v2, lb, lc) || !clipped_bounds(v0, v1, v2, rb, rc)) continue;   // (a sliver: leave the reference whole)
+                    TriInfo l, r;
+                    l.b = lc; r.b = rc;
+                    for (int k = 0; k < 3; ++k) { l.c[k] = 0.5f * (lc.lo[k] + lc.hi[k]); r.c[k] = 0.5f * (rc.lo[k] + rc.hi[k]); }
+                    tri[(size_t)c.ref] = l;
+                    const int32_t nr = (int32_t)tri.size();
+                    tri.push_back(r); ref_tri.push_back(f); order.push_back(nr);
+                    float sl = longest(lc, ax), sr = longest(rc, ax);
+                    if (sl > limit) { heap.push_back({sl, c.ref}); std::push_heap(heap.begin(), heap.end()); }
+                    if (sr > limit) { heap.push_back({sr, nr}); std::push_heap(heap.begin(), heap.end()); }
+                }
+            }
+        }
+    }
+    const int64_t nref = (int64_t)tri.size();
+
+    std::vector<Node2> nodes((size_t)(2 * nref));
     Builder bld;
     bld.tri = tri.data(); bld.order = order.data(); bld.nodes = nodes.data(); bld.max_leaf = 0;   // down to single triangles
-    bld.build(0, (int32_t)nf, 0);
+    bld.build(0, (int32_t)nref, 0);
     for (int k = 0; k < 3; ++k) { out.root_lo[k] = nodes[0].b.lo[k] - pad; out.root_hi[k] = nodes[0].b.hi[k] + pad; }
 
     // ---- collapse to `width`-wide nodes: SAH-optimal for the given binary topology (dynamic programming over "a subtree represented
@@ -200,7 +289,7 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
     }
     out.sah_cost = dp[0].c[0];
 
-    out.tri_order.reserve((size_t)nf);
+    out.tri_order.reserve((size_t)nref);
     struct Child { int32_t n2; bool leaf; };
     // the children a subtree contributes when it is given `slots` slots of its parent's wide node
     auto emit = [&](auto&& self, int32_t n, int slots, std::vector<Child>& outc) -> void {
@@ -240,7 +329,7 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
                 w.child[i] = -1;
                 w.leaf_start[i] = (int32_t)out.tri_order.size();
                 w.leaf_count[i] = c.ntri;
-                for (int32_t j = c.first; j < c.first + c.ntri; ++j) out.tri_order.push_back(order[(size_t)j]);
+                for (int32_t j = c.first; j < c.first + c.ntri; ++j) out.tri_order.push_back(ref_tri.empty() ? order[(size_t)j] : ref_tri[(size_t)order[(size_t)j]]);
             }
         }
         out.nodes[(size_t)it.wide] = w;

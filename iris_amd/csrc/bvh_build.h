@@ -20,7 +20,8 @@ struct WideNode {
 struct WideBvh {
     int width = 0;
     std::vector<WideNode> nodes;     // nodes[0] is the root; the internal children of a node are consecutive
-    std::vector<int32_t> tri_order;  // leaf order -> original triangle index; a node's leaf triangles are consecutive
+    std::vector<int32_t> tri_order;  // leaf order -> original triangle index; a node's leaf triangles are consecutive.  Longer than the mesh
+                                     // when long triangles were split into several references (presplit): those appear once per reference
     float root_lo[3], root_hi[3];
     int depth = 0;
     float sah_cost = 0.f;
@@ -30,8 +31,9 @@ struct WideBvh {
 // verts: (nv,3) f32, faces: (nf,3) i32.  leaf_tris: max triangles per leaf (1..7).  tri_cost: cost of one triangle test relative to
 // one wide-node visit in the SAH the collapse minimises (measured on the traversal kernels: ~70 against ~110 instructions).
 // Boxes are padded by `pad_rel * max(|coordinate|, extent)` so that the f32 slab test is conservative with respect to the
-// Moeller-Trumbore test (see DESIGN.md "closest-hit semantics").
+// Moeller-Trumbore test (see DESIGN.md "closest-hit semantics").  presplit: early split clipping of triangles whose box is longer than
+// presplit x the median triangle's (0 = off), see bvh_build.cpp.
 WideBvh build_wide_bvh(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int width, int leaf_tris,
-                       float pad_rel = 2e-5f, float tri_cost = 0.7f);
+                       float pad_rel = 2e-5f, float tri_cost = 0.7f, float presplit = 8.f);
 
 }  // namespace iris

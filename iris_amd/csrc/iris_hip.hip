@@ -40,12 +40,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
 
 // ---- diagnostics options (iris_hip_debug.h): process-wide, set by tests / experiments only; -1 = the built-in default
-static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1;
+static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1, g_opt_bvh_presplit_x10 = -1;
 extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     if (!key) return fail(IRIS_ERR_ARG, "iris_debug_set: null key");
     const std::string k(key);
     if (k == "bvh_max_leaf") g_opt_bvh_max_leaf = value;
     else if (k == "bvh_tri_cost_x100") g_opt_bvh_tri_cost_x100 = value;
+    else if (k == "bvh_presplit_x10") g_opt_bvh_presplit_x10 = value;
     else if (k == "phase_min") g_opt_phase_min = value;
     else if (k == "tile_target_rays") g_opt_tile_target_rays = value;
     else if (k == "tiles_per_block") g_opt_tiles_per_block = value;
@@ -121,7 +122,9 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     int max_leaf = 4;
     if (g_opt_bvh_max_leaf > 0) max_leaf = (int)std::min<long long>(7, g_opt_bvh_max_leaf);   // iris_debug_set("bvh_max_leaf")
     const float tri_cost = g_opt_bvh_tri_cost_x100 > 0 ? (float)g_opt_bvh_tri_cost_x100 * 0.01f : 0.7f;   // iris_debug_set("bvh_tri_cost_x100")
-    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost);
+    const float presplit = g_opt_bvh_presplit_x10 >= 0 ? (float)g_opt_bvh_presplit_x10 * 0.1f : 8.f;       // iris_debug_set("bvh_presplit_x10"); 0 = off
+    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit);
+    if (bvh.tri_order.size() >= (size_t)(1 << 26) - 1) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^26 leaf records");
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
 
     // ---- encode nodes ----
@@ -217,7 +220,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     if (g_opt_phase_min >= 0) s->dev.phase_min = (int)g_opt_phase_min;  // iris_debug_set("phase_min") (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
     s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth;
-    s->info.sah_cost = bvh.sah_cost;
+    s->info.sah_cost = bvh.sah_cost; s->info.n_leaf_records = (int32_t)nt;
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
     return IRIS_OK;

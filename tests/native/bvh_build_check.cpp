@@ -2,7 +2,9 @@
 //   g++ -O1 -g -fsanitize=address,undefined bvh_build_check.cpp ../../iris_amd/csrc/bvh_build.cpp -lpthread
 // (GPU AddressSanitizer is not available on the pool: sanitizers run on the CPU build only).  Builds trees over random
 // triangle soups, degenerate inputs and a grid, and checks the structural invariants the traversal kernels rely on.
+#include <algorithm>
 #include <cmath>
+#include <initializer_list>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -15,16 +17,21 @@ using namespace iris;
 static int fails = 0;
 #define CHECK(c, ...) do { if (!(c)) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); ++fails; } } while (0)
 
-static void check_tree(const char* name, const std::vector<float>& v, const std::vector<int32_t>& f, int width, int max_leaf) {
+static int64_t split_refs = 0;
+static void check_tree(const char* name, const std::vector<float>& v, const std::vector<int32_t>& f, int width, int max_leaf, int expect_split = -1) {
     const int64_t nv = (int64_t)v.size() / 3, nf = (int64_t)f.size() / 3;
     WideBvh b = build_wide_bvh(v.data(), nv, f.data(), nf, width, max_leaf);
     CHECK(!b.nodes.empty(), "%s: no root", name);
-    CHECK((int64_t)b.tri_order.size() == nf, "%s: tri_order has %zu entries for %lld triangles", name, b.tri_order.size(), (long long)nf);
+    const int64_t nr = (int64_t)b.tri_order.size();      // leaf records: one per triangle, more where long triangles were split (presplit)
+    CHECK(nr >= nf && nr <= nf + std::max<int64_t>(nf / 4, 1024), "%s: tri_order has %zu entries for %lld triangles", name, b.tri_order.size(), (long long)nf);
+    CHECK(expect_split < 0 || (expect_split > 0) == (nr > nf), "%s: %lld extra references, expected %s", name, (long long)(nr - nf), expect_split ? "some" : "none");
     std::vector<int> seen((size_t)nf, 0);
     for (int32_t t : b.tri_order) { CHECK(t >= 0 && t < nf, "%s: triangle id %d out of range", name, t); if (t >= 0 && t < nf) seen[(size_t)t]++; }
-    for (int64_t t = 0; t < nf; ++t) CHECK(seen[(size_t)t] == 1, "%s: triangle %lld referenced %d times", name, (long long)t, seen[(size_t)t]);
+    for (int64_t t = 0; t < nf; ++t) CHECK(seen[(size_t)t] >= 1, "%s: triangle %lld referenced %d times", name, (long long)t, seen[(size_t)t]);
     std::vector<int> node_ref(b.nodes.size(), 0);
-    std::vector<char> leaf_cover((size_t)nf, 0);
+    std::vector<char> leaf_cover((size_t)nr, 0);
+    struct LeafBox { float lo[3], hi[3]; };
+    std::vector<std::vector<LeafBox>> boxes_of((size_t)nf);     // split triangles: the leaf boxes of their references
     for (size_t i = 0; i < b.nodes.size(); ++i) {
         const WideNode& w = b.nodes[i];
         CHECK(w.n >= 0 && w.n <= width, "%s: node %zu has %d children", name, i, w.n);
@@ -37,11 +44,16 @@ static void check_tree(const char* name, const std::vector<float>& v, const std:
                 prev_child = w.child[s];
             } else {
                 CHECK(w.leaf_count[s] >= 1 && w.leaf_count[s] <= 7, "%s: leaf of %d triangles", name, w.leaf_count[s]);   // 3-bit count in the leaf reference
-                CHECK(w.leaf_start[s] >= 0 && (int64_t)w.leaf_start[s] + w.leaf_count[s] <= nf, "%s: leaf range", name);
-                for (int32_t j = w.leaf_start[s]; j < w.leaf_start[s] + w.leaf_count[s] && j < nf; ++j) {
+                CHECK(w.leaf_start[s] >= 0 && (int64_t)w.leaf_start[s] + w.leaf_count[s] <= nr, "%s: leaf range", name);
+                for (int32_t j = w.leaf_start[s]; j < w.leaf_start[s] + w.leaf_count[s] && j < nr; ++j) {
                     CHECK(!leaf_cover[(size_t)j], "%s: leaf slot %d covered twice", name, j);
                     leaf_cover[(size_t)j] = 1;
                     const int32_t t = b.tri_order[(size_t)j];
+                    if (seen[(size_t)t] > 1) {
+                        LeafBox lb; for (int a = 0; a < 3; ++a) { lb.lo[a] = w.lo[s][a]; lb.hi[a] = w.hi[s][a]; }
+                        boxes_of[(size_t)t].push_back(lb);
+                        continue;
+                    }
                     for (int k = 0; k < 3; ++k) {
                         const float* p = v.data() + (int64_t)f[(size_t)t * 3 + k] * 3;
                         for (int a = 0; a < 3; ++a)
@@ -53,9 +65,31 @@ static void check_tree(const char* name, const std::vector<float>& v, const std:
         }
     }
     for (size_t i = 1; i < b.nodes.size(); ++i) CHECK(node_ref[i] == 1, "%s: node %zu referenced %d times", name, i, node_ref[i]);
-    for (int64_t j = 0; j < nf; ++j) CHECK(leaf_cover[(size_t)j], "%s: leaf slot %lld not covered", name, (long long)j);
+    for (int64_t j = 0; j < nr; ++j) CHECK(leaf_cover[(size_t)j], "%s: leaf slot %lld not covered", name, (long long)j);
+    // a split triangle: every point of it lies in the (padded) leaf box of at least one of its references
+    std::mt19937 prng(11);
+    std::uniform_real_distribution<float> PU(0.f, 1.f);
+    for (int64_t t = 0; t < nf; ++t) {
+        if (boxes_of[(size_t)t].empty()) continue;
+        const float* p0 = v.data() + (int64_t)f[(size_t)t * 3] * 3; const float* p1 = v.data() + (int64_t)f[(size_t)t * 3 + 1] * 3; const float* p2 = v.data() + (int64_t)f[(size_t)t * 3 + 2] * 3;
+        for (int q = 0; q < 200; ++q) {
+            float a = PU(prng), c = PU(prng);
+            if (q < 3) { a = q == 1; c = q == 2; } else if (q < 40) { (q % 3 == 0 ? a : c) = 0.f; if (q % 3 == 2) c = 1.f - a; }   // vertices and edges first
+            if (a + c > 1.f) { a = 1.f - a; c = 1.f - c; }
+            double pt[3];
+            for (int k = 0; k < 3; ++k) pt[k] = (double)p0[k] + (double)a * ((double)p1[k] - p0[k]) + (double)c * ((double)p2[k] - p0[k]);
+            bool in = false;
+            for (const LeafBox& lb : boxes_of[(size_t)t]) {
+                bool ok = true;
+                for (int k = 0; k < 3; ++k) ok = ok && pt[k] >= lb.lo[k] && pt[k] <= lb.hi[k];
+                in = in || ok;
+            }
+            CHECK(in, "%s: a point of split triangle %lld (%d references) is in none of their leaf boxes", name, (long long)t, (int)boxes_of[(size_t)t].size());
+        }
+    }
+    split_refs = nr - nf;
     CHECK(3 * b.depth + 4 <= 96, "%s: depth %d too deep for the traversal stack", name, b.depth);
-    std::printf("ok %-28s nf=%-8lld nodes=%-8zu depth=%-3d sah=%.2f\n", name, (long long)nf, b.nodes.size(), b.depth, b.sah_cost);
+    std::printf("ok %-28s nf=%-8lld refs=%-8lld nodes=%-8zu depth=%-3d sah=%.2f\n", name, (long long)nf, (long long)nr, b.nodes.size(), b.depth, b.sah_cost);
 }
 
 int main() {
@@ -92,6 +126,15 @@ int main() {
         }
         check_tree("grid 64x64", v, f, 4, 4);
     }
+    {   // long triangles among fine detail (a decimated floor and a wall under a soup): split into clipped references
+        auto s = soup(20000, 0.03f, 4.f);
+        auto add = [&](std::initializer_list<float> pts) { int base = (int)s.first.size() / 3; for (float x : pts) s.first.push_back(x); for (int k = 0; k < 3; ++k) s.second.push_back(base + k); };
+        add({0, 0, 0, 4, 0, 0, 4, 4, 0}); add({0, 0, 0, 4, 4, 0, 0, 4, 0});           // floor
+        add({0, 0, 0, 0, 4, 4, 0, 0, 4}); add({0.5f, 0.2f, 3.9f, 3.7f, 3.1f, 0.1f, 3.9f, 3.3f, 0.2f});   // wall, a long diagonal sliver
+        check_tree("soup 20k + 4 long triangles", s.first, s.second, 4, 4, 1);
+        CHECK(split_refs >= 100, "long triangles: only %lld extra references", (long long)split_refs);
+    }
+    { auto s = soup(20000, 0.05f, 4.f); check_tree("soup 20k (uniform: no split)", s.first, s.second, 4, 4, 0); }
     if (fails) { std::printf("%d check(s) failed\n", fails); return 1; }
     std::printf("all BVH builder checks passed\n");
     return 0;

@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
     if (fread(verts.data(), 4, nv * 3, f) != (size_t)nv * 3 || fread(faces.data(), 4, nf * 3, f) != (size_t)nf * 3) return 1;
     fclose(f);
     auto t0 = std::chrono::steady_clock::now();
-    WideBvh bvh = build_wide_bvh(verts.data(), nv, faces.data(), nf, 4, max_leaf, 2e-5f, tri_cost);
+    const char* ps = getenv("BVH_EVAL_PRESPLIT");   // presplit factor (default 8, 0 = off)
+    WideBvh bvh = build_wide_bvh(verts.data(), nv, faces.data(), nf, 4, max_leaf, 2e-5f, tri_cost, ps ? (float)atof(ps) : 8.f);
     const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const size_t nn = bvh.nodes.size();
     // Q8 decode: per node, origin = min of child lows, per axis the smallest power of two 2^e with 255 * 2^e >= extent
@@ -145,9 +146,9 @@ int main(int argc, char** argv) {
     }
     size_t leaves = 0, leaf_tris = 0, children = 0;
     for (const auto& w : bvh.nodes) for (int s = 0; s < w.n; ++s) { ++children; if (w.child[s] < 0) { ++leaves; leaf_tris += w.leaf_count[s]; } }
-    printf("{\"triangles\": %lld, \"nodes\": %zu, \"depth\": %d, \"sah\": %.3f, \"build_s\": %.2f, \"children_per_node\": %.3f, \"tris_per_leaf\": %.3f, "
+    printf("{\"triangles\": %lld, \"leaf_records\": %zu, \"nodes\": %zu, \"depth\": %d, \"sah\": %.3f, \"build_s\": %.2f, \"children_per_node\": %.3f, \"tris_per_leaf\": %.3f, "
            "\"rays\": %d, \"hit_frac\": %.4f, \"nodes_per_ray\": %.3f, \"tris_per_ray\": %.3f, \"max_stack\": %lld, \"cull\": \"%s\", \"skipped_nodes_per_ray\": %.3f, \"skipped_leaves_per_ray\": %.3f}\n",
-           (long long)nf, nn, bvh.depth, bvh.sah_cost, build_s, (double)children / nn, (double)leaf_tris / leaves, n_rays, (double)hits / n_rays,
+           (long long)nf, bvh.tri_order.size(), nn, bvh.depth, bvh.sah_cost, build_s, (double)children / nn, (double)leaf_tris / leaves, n_rays, (double)hits / n_rays,
            (double)tot_nodes / n_rays, (double)tot_tris / n_rays, max_sp, cm ? cm : "none", (double)skipped_nodes / n_rays, (double)skipped_leaves / n_rays);
     return 0;
 }
