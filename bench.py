@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over (--per-lobe)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: bake only the stripes rank 0 of an N-GPU run would own (no collective), to "
                     "measure the per-rank time of a strong-scaling run on one GPU; the printed value is then NOT the headline metric")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="debug: the rank whose stripes --emulate-world bakes")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="iris_debug_set tuning option (experiments), e.g. bvh_max_leaf=2")
     ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
     args = ap.parse_args()
@@ -168,11 +169,12 @@ def main():
     K, c2w = synth.camera(H, W, 0)
     pix_local = sh.local_pixel_ids(H, W, world, rank, device=dev)
     if args.emulate_world > 1 and world == 1:
-        pix_local = sh.local_pixel_ids(H, W, args.emulate_world, 0, device=dev)
+        pix_local = sh.local_pixel_ids(H, W, args.emulate_world, args.emulate_rank % args.emulate_world, device=dev)
     rough = bs.roughness_levels().tolist()
     n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
     one_launch = args.variant == 0 and not args.per_lobe
 
+    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     ev_view = []     # (start, end, rays) HIP events around every bake_view_kernel launch of the timed region, on the launch stream
     ev_gather = []   # the same around the all_gather + permutation (N > 1)
 
@@ -212,17 +214,26 @@ def main():
             else:
                 maps[m, g["sel"]] = res[0]; maps[m + 1, g["sel"]] = res[1]; m += 2
         if world > 1:
-            if timed:
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record()
-            full = sh.gather_maps(maps, H, W, world, rank)
-            if timed:
-                g1.record(); ev_gather.append((g0, g1))
+            # the gather of this view runs on its own stream, beside the next view's kernels (bake_shading's CLI hands the maps to its
+            # writer threads the same way); the timed region ends with both streams joined
+            done = torch.cuda.Event()
+            done.record()
+            maps.record_stream(gather_stream)
+            with torch.cuda.stream(gather_stream):
+                gather_stream.wait_event(done)
+                if timed:
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record(gather_stream)
+                full = sh.gather_maps(maps, H, W, world, rank)
+                if timed:
+                    g1.record(gather_stream); ev_gather.append((g0, g1))
         else:
             full = maps
         return rays, full
 
     def sync():
+        if gather_stream is not None:
+            torch.cuda.current_stream().wait_stream(gather_stream)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -253,6 +264,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
         dist.all_reduce(ranks_seen, op=dist.ReduceOp.SUM)
+        # every rank must hold the same gathered image of the last view (sums in one fixed order: identical bits on identical data)
+        chk = full.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        gather_ok = bool(lo.item() == hi.item()) and bool(torch.isfinite(chk).item()) and float(chk.item()) > 0.0
     dt = float(t.item()); rays_total = float(rays_t.item())
     value = rays_total / dt / 1e6
 
@@ -266,7 +282,8 @@ def main():
                    "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"],
                            "sah_cost": round(info["sah_cost"], 3), "build_seconds": round(info["build_seconds"], 2)}},
         "multi_gpu": {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks_seen": int(ranks_seen.item()), "per_rank_ms_per_step": [round(x / max(args.steps, 1) * 1e3, 3) for x in per_rank],
-                      "gather_ms": round(float(np.mean([a.elapsed_time(b) for a, b in ev_gather])), 3) if ev_gather else None},
+                      "gather_ms": round(float(np.mean([a.elapsed_time(b) for a, b in ev_gather])), 3) if ev_gather else None,
+                      "gather_overlapped": world > 1, "gathered_image_identical_on_all_ranks": gather_ok if world > 1 else None},
     }
 
     if rank == 0 and not args.no_roofline and one_launch and ev_view:
