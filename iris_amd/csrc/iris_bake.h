@@ -206,11 +206,15 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     const int np = (int)min((int64_t)a.tile_px, a.P - p0);
     const int nr = np * spp;
 
+    // r / spp for a tile-local ray index without the 25-instruction integer division: exact for r * spp < 2^32 (r < kTileRays, spp <= kTileRays)
+    const uint32_t spp_m = spp > 1 ? (uint32_t)(0x100000000ull / (uint64_t)(uint32_t)spp) + 1u : 0u;
+    auto div_spp = [&](int r) -> int { return spp > 1 ? (int)__umulhi((uint32_t)r, spp_m) : r; };
+
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
     tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
         a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
         [&](int r) -> uint32_t {
-            const int pl = r / spp, s = r - pl * spp;
+            const int pl = div_spp(r), s = r - pl * spp;
             const int64_t p = p0 + pl;
             const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
             const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
@@ -223,7 +227,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
             return dir_bin(wi);
         },
         [&](int r, f3& o, f3& d) {
-            const int64_t p = p0 + r / spp;
+            const int64_t p = p0 + div_spp(r);
             o = ld3(a.pos + p * 3);                       // raw: the pixel's position; prepare() offsets it
             const float4 qa = res[r];
             d = mk3(qa.x, qa.y, qa.z);

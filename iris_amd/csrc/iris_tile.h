@@ -9,7 +9,7 @@ namespace iris {
 
 // Direction bin: octahedral map of the unit vector to [0,1)^2, 16x16 cells, Morton-interleaved (adjacent codes = adjacent cones)
 __device__ __forceinline__ uint32_t dir_bin(f3 d) {
-    float inv = 1.0f / (fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);
+    float inv = __builtin_amdgcn_rcpf(fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);    // (1 ulp is plenty for a bin: results do not depend on the binning)
     float px = d.x * inv, py = d.y * inv;
     if (d.z < 0.f) {
         float qx = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
