@@ -244,10 +244,58 @@ def output_files(output, im_id):
     return d + s
 
 
-def _write_atomic(exr, path, img, compression):
-    tmp = path + ".part"
-    exr.write_exr(tmp, img, compression)
-    os.replace(tmp, path)
+class MapWriter:
+    """The 13 maps of a view -> host -> 13 EXR files, off the critical path (bake_shading.py:131,202-203 write them synchronously).
+    submit() lays the maps out as the file stores them on the GPU (B,G,R planes per scanline block, ZIP's byte reordering + delta
+    predictor: utils/exr.scanline_blocks_torch), enqueues one device-to-host copy into pinned buffers on a side stream and returns; writer
+    threads wait for the copy's event, deflate and write, so the next view's kernels start while this view is still on its way to disk and
+    the host threads do nothing under the GIL but file I/O.  Two buffer sets: a third view waits for the first one's files.  Files appear
+    under their final name only when complete (the CLI's resume rule never sees a truncated file)."""
+
+    def __init__(self, device, img_hw, compression, n_maps=13, n_buffers=2):
+        from concurrent.futures import ThreadPoolExecutor
+        from .utils import exr
+        self.exr, self.compression, self.img_hw, self.n_buffers = exr, compression, tuple(img_hw), n_buffers
+        self.stream = torch.cuda.Stream(device=device)
+        self.bufs = None                                    # pinned (full, tail) pairs, sized at the first submit
+        self.busy = [[] for _ in range(n_buffers)]
+        self.pool = ThreadPoolExecutor(max_workers=max(1, min(n_maps, os.cpu_count() or 4)), thread_name_prefix="maps")
+        self.k = 0
+
+    def submit(self, files, maps_dev):
+        """maps_dev: (n_maps, H, W, 3) f32 on the device (R,G,B), produced on the current stream; files: n_maps paths."""
+        exr, (H, W) = self.exr, self.img_hw
+        full, tail = exr.scanline_blocks_torch(maps_dev, self.compression)
+        if self.bufs is None:
+            self.bufs = [(torch.empty(full.shape, dtype=torch.uint8).pin_memory(), torch.empty(tail.shape, dtype=torch.uint8).pin_memory())
+                         for _ in range(self.n_buffers)]
+        i = self.k % self.n_buffers; self.k += 1
+        for f in self.busy[i]:
+            f.result()                                      # this buffer's previous files are on disk (re-raises a writer's exception)
+        ready = torch.cuda.Event(); ready.record()
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            self.bufs[i][0].copy_(full, non_blocking=True)
+            self.bufs[i][1].copy_(tail, non_blocking=True)
+            done.record(self.stream)
+        full.record_stream(self.stream); tail.record_stream(self.stream)
+        hfull, htail = self.bufs[i][0].numpy(), self.bufs[i][1].numpy()
+        chunks = exr.chunk_pool() if (os.cpu_count() or 1) > 16 else None     # more cores than files in flight: deflate block-parallel
+
+        def write(path, j):
+            done.synchronize()
+            tmp = path + ".part"
+            exr.write_exr_blocks(tmp, H, W, self.compression, hfull[j], htail[j], pool=chunks)
+            os.replace(tmp, path)
+        self.busy[i] = [self.pool.submit(write, f, j) for j, f in enumerate(files)]
+
+    def close(self):
+        for fs in self.busy:
+            for f in fs:
+                f.result()
+        self.busy = [[] for _ in range(self.n_buffers)]
+        self.pool.shutdown()
 
 
 def main(argv=None):
@@ -312,9 +360,7 @@ def main(argv=None):
     if args.denoise == "atrous":
         from .utils.denoise import Denoiser
         denoiser = Denoiser(img_hw[::-1], device)          # denoiser = mitsuba.OptixDenoiser(img_hw[::-1])   (:81)
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=min(13, os.cpu_count() or 4))
-    pending = []
+    writer = MapWriter(device, img_hw, args.compression)
     start_time = time.time()
     rays = 0
     for im_id in range(rank, len(views), world):           # views shard over ranks with no collective: one file set per view
@@ -326,17 +372,10 @@ def main(argv=None):
         # across the training views; keyed on the view id (not on the rank), so that results do not depend on how views are sharded
         out = bake_view(scene, emitter, xs, ds, args.spp_diffuse, args.spps_specular, seed=view_seed(args.seed, im_id), image_width=img_hw[1], denoiser=denoiser)
         rays += out["rays"]
-        # 13 maps -> host once, then the files are compressed and written by a thread pool while the next view bakes (zlib and numpy
-        # release the GIL; a 1080p ZIP map costs ~1 s of CPU, the bake of the whole view 0.3 s of GPU).  Files appear under their final
-        # name only when complete, so that the resume rule above never sees a truncated file.
-        maps = torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3).cpu().numpy()
-        while len(pending) >= 2 * 13:                      # at most two views of host buffers in flight
-            pending.pop(0).result()
-        for f, m in zip(files, maps):
-            pending.append(pool.submit(_write_atomic, exr, f, m, args.compression))
-    for p in pending:
-        p.result()
-    pool.shutdown()
+        # 13 maps -> pinned host buffer on a side stream -> compressed and written by threads while the next view bakes (a 1080p ZIP map
+        # costs ~1 s of CPU, the bake of the whole view 0.3 s of GPU)
+        writer.submit(files, torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3))
+    writer.close()
     torch.cuda.synchronize()
     dt = time.time() - start_time
     print("[bake_shading] rank {}: {} rays in {:.2f} s ({:.1f} Mrays/s incl. file I/O)".format(rank, rays, dt, rays / max(dt, 1e-9) / 1e6))

@@ -16,7 +16,7 @@ import time
 import torch
 
 from . import _lib as L
-from .bake_shading import N_ROUGHNESS, _write_atomic, output_files, roughness_levels
+from .bake_shading import N_ROUGHNESS, MapWriter, output_files, roughness_levels
 from .utils.path_tracing import path_tracing_det_diff, path_tracing_det_spec, ray_intersect
 
 SPP_DIFFUSE = 128          # refine_shading.py:103
@@ -156,9 +156,8 @@ def main(argv=None):
     if args.denoise == "atrous":
         from .utils.denoise import Denoiser
         denoiser = Denoiser(img_hw[::-1], device)
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=min(13, os.cpu_count() or 4))
-    pending, start_time = [], time.time()
+    writer = MapWriter(device, img_hw, args.compression)
+    start_time = time.time()
     for im_id in range(rank, len(views), world):
         files = output_files(args.output, im_id)
         if not args.overwrite and all(os.path.exists(f) for f in files):
@@ -166,14 +165,8 @@ def main(argv=None):
         torch.manual_seed(args.seed * 1000003 + im_id); torch.cuda.manual_seed(args.seed * 1000003 + im_id)     # the integrators draw with torch.rand
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
         out = refine_view(scene, emitter, material_net, xs, ds, args.spp_diffuse, args.spp_specular, args.indir_depth, denoiser=denoiser)
-        maps = torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3).cpu().numpy()
-        while len(pending) >= 2 * 13:
-            pending.pop(0).result()
-        for f, m in zip(files, maps):
-            pending.append(pool.submit(_write_atomic, exr, f, m, args.compression))
-    for p in pending:
-        p.result()
-    pool.shutdown()
+        writer.submit(files, torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3))
+    writer.close()
     torch.cuda.synchronize()
     print("[refine_shading] rank {}: {:.2f} s".format(rank, time.time() - start_time))
 

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""End-to-end wall clock of the bake_shading CLI (reference: bake_shading.py as run by scripts/*/train.sh): the bench workload written
+to disk in the reference's file formats (scene.ply, vslf.npz, emitter.pth, camera JSON), then `python -m iris_amd.bake_shading` over a
+sequence of 1080p views -- mesh load + BVH build, per view rays / primary hits / 7-lobe bake / denoise, 13 EXR files per view.
+bench.py times the path with inputs resident in HBM; this is the number a user of the CLI sees.  One JSON line per configuration.
+
+    python tools/bench_cli.py [--views 8] [--tris 1000000] [--out /tmp/iris_cli]
+"""
+import argparse
+import json
+import os
+import shutil
+import struct
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def write_ply(path, v, f):
+    with open(path, "wb") as fh:
+        fh.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                  "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(v), len(f))).encode())
+        fh.write(np.ascontiguousarray(v, "<f4").tobytes())
+        rec = np.empty(len(f), dtype=[("n", "u1"), ("i", "<i4", 3)])
+        rec["n"] = 3; rec["i"] = f
+        fh.write(rec.tobytes())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--slf-res", type=int, default=256)
+    ap.add_argument("--out", type=str, default="/tmp/iris_cli")
+    ap.add_argument("--configs", type=str, default="zip:atrous,none:atrous,none:none")
+    args = ap.parse_args()
+    from tools import synth
+    shutil.rmtree(args.out, ignore_errors=True)
+    scene_dir = os.path.join(args.out, "scene"); os.makedirs(scene_dir)
+    t0 = time.time()
+    room = synth.room(1, args.tris)
+    v, f = room["vertices"].astype(np.float32), room["faces"].astype(np.int32)
+    write_ply(os.path.join(scene_dir, "scene.ply"), v, f)
+    slf = synth.slf_for(v, f, H=args.slf_res)
+    emi = synth.emitters_for(v, f, room["is_emitter"])
+    from iris_amd.model.slf import VoxelSLF
+    vs = VoxelSLF(torch.from_numpy(slf["mask"]), float(slf["voxel_min"]), float(slf["voxel_max"]))
+    vs.radiance[:] = torch.from_numpy(slf["radiance"])
+    slf_path, emi_path = os.path.join(args.out, "vslf.npz"), os.path.join(args.out, "emitter.pth")
+    torch.save({"mask": torch.from_numpy(slf["mask"]), "voxel_min": float(slf["voxel_min"]), "voxel_max": float(slf["voxel_max"]), "weight": vs.state_dict()}, slf_path)
+    torch.save({"is_emitter": torch.from_numpy(emi["is_emitter"]), "emitter_vertices": torch.from_numpy(emi["emitter_vertices"]),
+                "emitter_area": torch.from_numpy(emi["emitter_area"]), "emitter_normal": torch.zeros(len(emi["emitter_area"]), 3),
+                "emitter_radiance": torch.from_numpy(emi["emitter_radiance"])}, emi_path)
+    H, W = args.height, args.width
+    views = []
+    for i in range(args.views):
+        K, c2w = synth.camera(H, W, (i * 32) // args.views, n_views=32)
+        views.append({"K": np.asarray(K).reshape(-1).tolist(), "c2w": np.asarray(c2w).reshape(-1).tolist()})
+    cam_path = os.path.join(args.out, "cameras.json")
+    json.dump({"img_hw": [H, W], "views": views}, open(cam_path, "w"))
+    print("# dataset written in %.1f s: %d triangles, %d views of %dx%d" % (time.time() - t0, len(f), args.views, W, H), file=sys.stderr)
+
+    for cfg in args.configs.split(","):
+        comp, den = cfg.split(":")
+        out_dir = os.path.join(args.out, "shading_" + cfg.replace(":", "_"))
+        cmd = [sys.executable, "-m", "iris_amd.bake_shading", "--scene", scene_dir, "--slf_path", slf_path, "--emitter_path", emi_path, "--output", out_dir,
+               "--dataset", "generic", "--cameras", cam_path, "--compression", comp, "--denoise", den]
+        t = time.time()
+        r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True)
+        dt = time.time() - t
+        if r.returncode != 0:
+            print(r.stdout[-2000:], r.stderr[-2000:], file=sys.stderr)
+            raise SystemExit("bake_shading failed")
+        inner = [l for l in r.stdout.splitlines() if l.startswith("[bake_shading]")]
+        n_files = sum(len(fs) for _, _, fs in os.walk(out_dir))
+        size = sum(os.path.getsize(os.path.join(d, x)) for d, _, fs in os.walk(out_dir) for x in fs)
+        from iris_amd import bake_shading as bs
+        rays = args.views * H * W * (bs.SPP_DIFFUSE + sum(bs.SPPS_SPECULAR))     # upper bound: every pixel valid
+        print(json.dumps({"config": {"compression": comp, "denoise": den, "views": args.views, "image": [W, H], "triangles": int(len(f)), "host_cpus": os.cpu_count()},
+                          "wall_s": round(dt, 2), "s_per_view_incl_startup": round(dt / args.views, 3), "cli_report": inner[-1] if inner else None,
+                          "files": n_files, "bytes_written": size, "upper_bound_Mrays_per_s": round(rays / dt / 1e6, 1)}), flush=True)
+        shutil.rmtree(out_dir, ignore_errors=True)
+    shutil.rmtree(args.out, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
