@@ -35,9 +35,9 @@ def _predict(raw):
 
 
 def _unpredict(pred):
-    d = np.frombuffer(pred, np.uint8).astype(np.int64)
-    d[1:] -= 128
-    t = (np.cumsum(d) & 0xFF).astype(np.uint8)
+    d = np.frombuffer(pred, np.uint8).copy()
+    d[1:] -= 128                                                    # uint8 arithmetic wraps: modulo 256, as the format defines it
+    t = np.cumsum(d, dtype=np.uint8)
     half = (len(pred) + 1) // 2
     out = np.empty(len(pred), np.uint8)
     out[0::2] = t[:half]
@@ -212,6 +212,12 @@ def read_exr(path):
         raw = buf[o + 8:o + 8 + sz]
         if comp != _COMP_NONE:
             raw = _zip_decompress(raw, row_bytes * nl)
+        types = {t for _, t in info["channels"]}
+        if len(types) == 1:                                          # (the usual case) one pixel type: the block is an (nl, channels, W) array
+            blk = np.frombuffer(raw, dts[types.pop()], nl * len(info["channels"]) * W).reshape(nl, len(info["channels"]), W)
+            for ci, (n, _) in enumerate(info["channels"]):
+                out[n][y0:y0 + nl] = blk[:, ci]
+            continue
         p = 0
         for ly in range(nl):
             for n, t in info["channels"]:

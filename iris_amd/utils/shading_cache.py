@@ -67,12 +67,22 @@ class ShadingCache:
         first = exr.read_exr(os.path.join(cache_dir, "diffuse", "%03d.exr" % 0))
         hw = first.shape[0] * first.shape[1]
         c = cls(hw * n_views, roughness_level, device)
-        for i in range(n_views):
-            rd = lambda *p: torch.from_numpy(np.ascontiguousarray(exr.read_exr(os.path.join(cache_dir, *p)))).to(device)
-            d = rd("diffuse", "%03d.exr" % i)
-            s0 = [rd("specular", "%03d_0_%d.exr" % (i, j)) for j in range(roughness_level)]
-            s1 = [rd("specular", "%03d_1_%d.exr" % (i, j)) for j in range(roughness_level)]
-            c.put_view(i * hw, d, s0, s1)
+        # the files of a few views are inflated concurrently (zlib and the large numpy operations release the GIL): a ZIP map takes ~0.2 s
+        from concurrent.futures import ThreadPoolExecutor
+        rd = lambda *p: np.ascontiguousarray(exr.read_exr(os.path.join(cache_dir, *p)))
+        up = lambda a: torch.from_numpy(a).to(device)
+        with ThreadPoolExecutor(max_workers=max(1, min(32, os.cpu_count() or 4))) as pool:
+            def submit(i):
+                return (pool.submit(rd, "diffuse", "%03d.exr" % i),
+                        [pool.submit(rd, "specular", "%03d_0_%d.exr" % (i, j)) for j in range(roughness_level)],
+                        [pool.submit(rd, "specular", "%03d_1_%d.exr" % (i, j)) for j in range(roughness_level)])
+            ahead = 2                                                # views being read while view i is uploaded: bounds the host memory
+            pending = [submit(i) for i in range(min(ahead, n_views))]
+            for i in range(n_views):
+                d, s0, s1 = pending.pop(0)
+                if i + ahead < n_views:
+                    pending.append(submit(i + ahead))
+                c.put_view(i * hw, up(d.result()), [up(f.result()) for f in s0], [up(f.result()) for f in s1])
         return c
 
     def gather(self, idx=None):
