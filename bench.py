@@ -36,6 +36,14 @@ def build_workload(args, dev):
     from iris_amd.utils.path_tracing import Scene
     import tempfile
     room = synth.room(args.scene_seed, args.tris)
+    if getattr(args, "long_walls", False):
+        # (parity runs) the six walls once more as 12 large triangles 2 cm inside: what a decimated scan looks like to the BVH builder
+        v, f = room["vertices"], room["faces"]
+        lo, hi = v.min(0) + 0.02, v.max(0) - 0.02
+        c = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], v.dtype)
+        quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+        nf = np.array([[len(v) + a for a in (q[0], q[1], q[2])] for q in quads] + [[len(v) + a for a in (q[0], q[2], q[3])] for q in quads], f.dtype)
+        room = dict(room, vertices=np.concatenate([v, c]), faces=np.concatenate([f, nf]), is_emitter=np.concatenate([room["is_emitter"], np.zeros(len(nf), bool)]))
     slf = synth.slf_for(room["vertices"], room["faces"], args.slf_res)
     emi = synth.emitters_for(room["vertices"], room["faces"], room["is_emitter"])
     tmp = tempfile.mkdtemp(prefix="iris_bench_")

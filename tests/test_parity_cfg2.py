@@ -37,19 +37,20 @@ def _rel(a, b, mask=None):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-@pytest.mark.timeout(1500)
-def test_cfg2_all_maps_vs_literal_oracle(oracle_mod):
+def parity_table(oracle_mod, scene_seed=1, tris=1_000_000, view=0, long_walls=False):
+    """(config string, per-map rows, all bars met) for one view; also used by tools/parity_more.py for further scenes / views.
+    long_walls: the room's six walls added once more as 12 large triangles 2 cm inside (split into clipped references by the builder)."""
     import bench
     from iris_amd import bake_shading as bs
     from iris_amd.utils.dataset import real_ldr
     from tools import synth
     dev = torch.device("cuda:0")
-    args = argparse.Namespace(scene_seed=1, tris=1_000_000, slf_res=256, layout=0)
+    args = argparse.Namespace(scene_seed=scene_seed, tris=tris, slf_res=256, layout=0, long_walls=long_walls)
     room, slf_np, emi_np, scene, emitter = bench.build_workload(args, dev)
     osc = oracle_mod.Scene(room["vertices"], room["faces"])
     oslf = oracle_mod.VoxelSLF(slf_np["inds"], slf_np["radiance"], slf_np["voxel_min"], slf_np["voxel_max"])
     oem = oracle_mod.SLFEmitter(emi_np["is_emitter"], emi_np["emitter_radiance"], emi_np["emitter_area"], oslf)
-    K, c2w = synth.camera(H, W, 0)
+    K, c2w = synth.camera(H, W, view)
     xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
     g = bs.primary_hits(scene, xs, ds)
     pos, nrm, wo, pix = (g[k].cpu().numpy() for k in ("position", "normal", "wo", "pix_id"))
@@ -84,7 +85,16 @@ def test_cfg2_all_maps_vs_literal_oracle(oracle_mod):
                    "bit_exact_vs_device_arithmetic_oracle": True}
             table.append(row)
             ok &= row["flip_rate"] <= 2.5e-5 and row["rel_l2_without_flipped_pixels"] <= 1e-6 and row["rel_l2_whole_map"] <= 2.5e-3
-    out = {"config": f"BASELINE configs[1]: {W}x{H}, SPP {SPP}, room seed 1, {room['faces'].shape[0]} triangles, SLF H=256, Philox seed 0, valid pixels {P}",
+    info = scene.info()
+    cfg = (f"BASELINE configs[1]: {W}x{H}, SPP {SPP}, room seed {scene_seed}, view {view}, {room['faces'].shape[0]} triangles"
+           f"{' incl. 12 wall triangles' if long_walls else ''} ({info['n_leaf_records']} leaf records), SLF H=256, Philox seed 0, valid pixels {P}")
+    return cfg, table, ok
+
+
+@pytest.mark.timeout(1500)
+def test_cfg2_all_maps_vs_literal_oracle(oracle_mod):
+    cfg, table, ok = parity_table(oracle_mod)
+    out = {"config": cfg,
            "bars": {"flip_rate": 2.5e-5, "rel_l2_without_flipped_pixels": 1e-6, "rel_l2_whole_map": 2.5e-3, "north_star_rel_l2": 1e-4}, "maps": table}
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "parity_cfg2.json"), "w") as fh:

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""The parity table of tests/test_parity_cfg2.py (HIP vs the device-arithmetic oracle bit for bit; vs the literal oracle flip rate and
+rel-L2 with / without flipped pixels, all 13 maps at BASELINE configs[1] size) on further scenes and views, including a room with
+two-triangle walls whose long triangles the BVH builder splits into clipped references.  Writes gpurun_out/parity_cfg2_more.json
+(kept under profiles/).    python tools/parity_more.py"""
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def main():
+    import conftest                                   # noqa: F401  (REPO paths)
+    import test_parity_cfg2 as t
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle as oracle_mod
+    oracle_mod.build()
+    cases = [dict(scene_seed=2, view=5), dict(scene_seed=3, view=17), dict(scene_seed=1, view=11, tris=200_000), dict(scene_seed=1, view=3, tris=200_000, long_walls=True)]
+    out, all_ok = [], True
+    for c in cases:
+        cfg, table, ok = t.parity_table(oracle_mod, **c)
+        all_ok &= ok
+        out.append({"config": cfg, "bars_met": bool(ok), "worst": {"flip_rate": max(r["flip_rate"] for r in table), "rel_l2_without_flipped_pixels": max(r["rel_l2_without_flipped_pixels"] for r in table),
+                                                                    "rel_l2_whole_map": max(r["rel_l2_whole_map"] for r in table)}, "maps": table})
+        print(cfg, "OK" if ok else "BARS MISSED", out[-1]["worst"], flush=True)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    json.dump({"bars": {"flip_rate": 2.5e-5, "rel_l2_without_flipped_pixels": 1e-6, "rel_l2_whole_map": 2.5e-3}, "cases": out}, open(os.path.join(REPO, "gpurun_out", "parity_cfg2_more.json"), "w"), indent=1)
+    return 0 if all_ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
