@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over (--per-lobe)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: bake only the stripes rank 0 of an N-GPU run would own (no collective), to "
                     "measure the per-rank time of a strong-scaling run on one GPU; the printed value is then NOT the headline metric")
+    ap.add_argument("--long-walls", action="store_true", help="experiments: add the room's six walls once more as 12 large triangles (a decimated scan; see build_workload)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="debug: the rank whose stripes --emulate-world bakes")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="iris_debug_set tuning option (experiments), e.g. bvh_max_leaf=2")
     ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
