@@ -200,6 +200,20 @@ def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du,
     draws the reference makes, [rand(2,B,spp,1), rand(N), rand(N,2), rand(N), rand(N,2)] (parity mode).
     Returns L Bx3, differentiable with respect to emitter_net.radiance.
     """
+    return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, 0, uniforms)
+
+
+def path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms=None):
+    """The full integrator render.py uses (utils/path_tracing.py:214-318): the first bounce of path_tracing_single -- with the radiance
+    cache consulted at roughness > 0.6 (eval_emitter's default trace_roughness; path_tracing_single passes 0.0) and the MIS denominator of
+    the emitter sample unclamped (:260 against :366) -- and every path whose sampled hit is neither an emitter nor a cached diffuse
+    surface continued by trace_indirect for up to indir_depth bounces, added with the BRDF weight (:300-316, under no_grad: gradient flows
+    through the first bounce only, as in the reference).  uniforms: the five draws of the first bounce, then trace_indirect's four per bounce.
+    Returns L Bx3, differentiable with respect to emitter_net.radiance."""
+    return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, int(indir_depth), uniforms, full=True)
+
+
+def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, full=False):
     rays_o = L.require_gpu(rays_o, torch.float32, "rays_o").reshape(-1, 3)
     rays_d = L.require_gpu(rays_d, torch.float32, "rays_d").reshape(-1, 3)
     dx_du = L.require_gpu(dx_du, torch.float32, "dx_du").reshape(-1, 3)
@@ -240,7 +254,7 @@ def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du,
         s1, s2 = nxt(N), nxt(N, 2)
         coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
         L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
-                                L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 1e-6, L.stream()))
+                                L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 0.0 if full else 1e-6, L.stream()))
         # BRDF sampling + next intersection (:384-391)
         s1b, s2b = nxt(N), nxt(N, 2)
         wi_b = torch.empty(N, 3, device=dev); pdf_b = torch.empty(N, device=dev); w_b = torch.empty(N, 3, device=dev)
@@ -252,8 +266,14 @@ def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du,
         rough_n = mat_next["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
         # eval_emitter at the sampled hit + MIS (:394-404)
         coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
+        hit_valid = torch.empty(N, device=dev, dtype=torch.bool) if full else None
         L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi_b), L.ptr(tri_n), L.ptr(rough_n), L.ptr(pdf_b), L.ptr(w_b), N,
-                                        L.ptr(coef2), L.ptr(const2), L.ptr(e2), None, 0.0, 1e-6, L.stream()))
+                                        L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(hit_valid) if full else None, 0.6 if full else 0.0, 1e-6, L.stream()))
+        if full and indir_depth > 0:
+            keep = torch.nonzero(hit_valid, as_tuple=False).reshape(-1)
+            L_indir = trace_indirect(scene, emitter_net, material_net, pos_n[keep].contiguous(), (-wi_b[keep]).contiguous(), nrm_n[keep].contiguous(), indir_depth,
+                                     uniforms=u)                                  # (u: what is left of the recorded draws, or None)
+            const2[keep] = const2[keep] + w_b[keep] * L_indir                     # rides on the constant term: no gradient, as in the reference
     return _PtAccumulate.apply(radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp)
 
 

@@ -313,9 +313,11 @@ def sample_brdf(s1, s2, wo, normal, mat):
     return wi, pdf, w
 
 
-def path_tracing_single(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_dv, spp, uniforms, radiance=None):
+def path_tracing_single(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_dv, spp, uniforms, radiance=None, trace_roughness=0.0, indir_depth=0):
     """utils/path_tracing.py:320-407.  material_fn(position ndarray) -> dict of ndarrays.  uniforms: the five draws.
-    Returns (L (B,3), terms) where terms lets grad_radiance() form dL/d radiance analytically."""
+    Returns (L (B,3), terms) where terms lets grad_radiance() form dL/d radiance analytically.
+    indir_depth > 0 (with trace_roughness 0.6 and the draws of trace_indirect appended): path_tracing, :214-318 -- the same first bounce, the
+    paths whose sampled hit is valid continued by trace_indirect (no gradient) and added with the BRDF weight."""
     rays_o = _f32(rays_o); rays_d = _f32(rays_d); dx_du = _f32(dx_du); dy_dv = _f32(dy_dv); B = rays_o.shape[0]
     rad = emitter.radiance if radiance is None else _f32(radiance).reshape(-1, 3)
     u = [np.ascontiguousarray(np.asarray(x, np.float32)) for x in uniforms]
@@ -334,19 +336,23 @@ def path_tracing_single(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_d
     s1, s2, s1b, s2b = u[1].reshape(-1), u[2].reshape(-1, 2), u[3].reshape(-1), u[4].reshape(-1, 2)
     coef1 = np.empty((N, 3), np.float32); e1 = np.empty(N, np.int32)
     lib().orc_pt_nee(scene.h, emitter.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(coef1), _p(e1),
-                     C.c_float(1e-6), C.c_float(1e-6), C.c_float(1e-6))
+                     C.c_float(1e-6), C.c_float(1e-6), C.c_float(0.0 if indir_depth > 0 else 1e-6))     # path_tracing (:260) does not clamp the MIS denominator, path_tracing_single (:366) does
     wi_b = np.empty((N, 3), np.float32); pdf_b = np.empty(N, np.float32); w_b = np.empty((N, 3), np.float32)
     pos_n = np.empty((N, 3), np.float32); nrm_n = np.empty((N, 3), np.float32); tri_n = np.empty(N, np.int64); hit_n = np.empty(N, np.uint8)
     lib().orc_pt_brdf_trace(scene.h, _p(pos), _p(nrm), _p(wo), _p(a), _p(r), _p(m), _p(s1b), _p(s2b), C.c_int64(N), _p(wi_b), _p(pdf_b), _p(w_b),
                             _p(pos_n), _p(nrm_n), _p(tri_n), _p(hit_n), C.c_int(0), C.c_float(0.0))
     _, r_n, _ = _mat(material_fn(pos_n))
-    coef2 = np.empty((N, 3), np.float32); const2 = np.empty((N, 3), np.float32); e2 = np.empty(N, np.int32)
+    coef2 = np.empty((N, 3), np.float32); const2 = np.empty((N, 3), np.float32); e2 = np.empty(N, np.int32); vn = np.empty(N, np.uint8)
     lib().orc_pt_brdf_finish(emitter.h, emitter.slf.h, _p(pos), _p(pos_n), _p(nrm_n), _p(wi_b), _p(tri_n), _p(r_n), _p(pdf_b), _p(w_b), C.c_int64(N),
-                             _p(coef2), _p(const2), _p(e2), None, C.c_float(0.0), C.c_float(1e-6))
+                             _p(coef2), _p(const2), _p(e2), _p(vn), C.c_float(trace_roughness), C.c_float(1e-6))
+    if indir_depth > 0:                                     # :300-316
+        keep = vn.astype(bool)
+        Li = trace_indirect(scene, emitter, material_fn, pos_n[keep], -wi_b[keep], nrm_n[keep], indir_depth, u[5:])
+        const2[keep] = const2[keep] + w_b[keep] * Li         # (f32: one product, one sum per component)
     Lout = np.empty((B, 3), np.float32)
     lib().orc_pt_accumulate(_p(rad), _p(e0), _p(path_of), _p(e1), _p(coef1), _p(e2), _p(coef2), _p(const2), C.c_int64(B), C.c_int(spp), _p(Lout))
     terms = {"e0": e0, "path_of": path_of, "e1": e1, "coef1": coef1, "e2": e2, "coef2": coef2, "const2": const2, "B": B, "spp": spp,
-             "tri_next": tri_n, "position": pos, "position_next": pos_n}
+             "tri_next": tri_n, "position": pos, "position_next": pos_n, "valid_next": vn.astype(bool), "brdf_weight": w_b}
     return Lout, terms
 
 
@@ -388,6 +394,11 @@ def _apply(Lacc, rows, throughput, radiance, e, coef, cst, weight):
         throughput *= weight
 
 
+def path_tracing(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, radiance=None):
+    """utils/path_tracing.py:214-318 (render.py's integrator).  uniforms: the 5 draws of the first bounce, then trace_indirect's 4 per bounce."""
+    return path_tracing_single(scene, emitter, material_fn, rays_o, rays_d, dx_du, dy_dv, spp, uniforms, radiance, trace_roughness=0.6, indir_depth=indir_depth)
+
+
 def trace_indirect(scene, emitter, material_fn, position, wo, normal, indir_depth, uniforms):
     """utils/path_tracing.py:409-502"""
     position = _f32(position); wo = _f32(wo); normal = _f32(normal); B = position.shape[0]
@@ -403,6 +414,7 @@ def trace_indirect(scene, emitter, material_fn, position, wo, normal, indir_dept
             mat = _mat(material_fn(position))
         a, r, m = mat
         s1, s2 = u.pop(0).reshape(-1), u.pop(0).reshape(-1, 2)
+        assert s1.shape[0] == N and s2.shape[0] == N, f"trace_indirect depth {depth}: {N} paths but draws for {s1.shape[0]} (the recorded uniforms belong to another path set)"
         coef1 = np.empty((N, 3), np.float32); e1 = np.empty(N, np.int32)
         lib().orc_pt_nee(scene.h, emitter.h, _p(position), _p(normal), _p(wo), _p(a), _p(r), _p(m), _p(s1), _p(s2), C.c_int64(N), _p(coef1), _p(e1),
                          C.c_float(1e-12), C.c_float(1e-12), C.c_float(0.0))

@@ -128,3 +128,55 @@ def test_hip_path_tracing_single_forward_backward(tmp_path, oracle_mod):
     (g2,) = torch.autograd.grad(L2.sum(), em.radiance)
     assert torch.isfinite(L2).all() and torch.isfinite(g2).all()
     assert int((g2.abs().sum(-1) > 0).sum()) <= int(g["is_emitter"].sum())
+
+
+# --------------------------------------------------------------------------------------------------------- path_tracing (render.py's integrator)
+def _full(oracle_mod):
+    g, p = golden("bake_box.npz"), golden("pt_full.npz")
+    sc = oracle_mod.Scene(g["verts"], g["faces"])
+    slf = oracle_mod.VoxelSLF(g["slf_inds"], g["slf_radiance"], float(g["voxel_min"]), float(g["voxel_max"]))
+    em = oracle_mod.SLFEmitter(g["is_emitter"], p["radiance"], g["emitter_area"], slf, p["emitter_vertices"], p["emitter_cdf"])
+    return g, p, sc, em, [p[f"u_{k}"] for k in range(int(p["n_u"]))]
+
+
+def test_oracle_path_tracing_full(oracle_mod, omode):
+    """utils/path_tracing.py:214-318 against the reference's own output (tests/golden/pt_full.npz: 17 recorded draws, indir_depth 3):
+    the first bounce alone (the reference run with indir_depth 0 on the same draws) and with the continuation."""
+    g, p, sc, em, us = _full(oracle_mod)
+    args = (sc, em, stub_material_np, p["rays_o"], p["rays_d"], p["dx_du"], p["dy_dv"], int(p["spp"]))
+    L0, t0 = oracle_mod.path_tracing_single(*args, us[:5], trace_roughness=0.6)
+    assert rel_l2(L0, p["L_first_bounce"]) <= 1e-5
+    assert int(t0["valid_next"].sum()) == us[5].shape[0]                 # the paths the reference continued
+    L, _ = oracle_mod.path_tracing(*args, int(p["indir_depth"]), us)
+    assert rel_l2(L, p["L"]) <= 1e-5
+    assert rel_l2(p["L"], p["L_first_bounce"]) > 1e-2                    # (the continuation is not a rounding error of the total)
+
+
+@pytest.mark.gpu
+def test_hip_path_tracing_full(tmp_path, oracle_mod):
+    from iris_amd.utils.path_tracing import path_tracing
+    dev = torch.device("cuda:0")
+    g, _, sc, em = _gpu_setup(tmp_path, dev)
+    _, p, osc, oem, us = _full(oracle_mod)
+    assert np.array_equal(em.radiance.detach().cpu().numpy(), p["radiance"])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rays = (T(p["rays_o"]), T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]))
+    L = path_tracing(sc, em, StubMaterial(), *rays, int(p["spp"]), int(p["indir_depth"]), uniforms=[T(u) for u in us])
+    assert L.shape == (p["rays_o"].shape[0], 3) and L.requires_grad
+    assert rel_l2(L.detach().cpu().numpy(), p["L"]) <= 1e-5                  # vs the reference
+    L0 = path_tracing(sc, em, StubMaterial(), *rays, int(p["spp"]), 0, uniforms=[T(u) for u in us[:5]])
+    assert rel_l2(L0.detach().cpu().numpy(), p["L_first_bounce"]) <= 1e-5
+    with oracle_mod.device_arithmetic():                                     # bit for bit against the device-arithmetic oracle
+        oL, terms = oracle_mod.path_tracing(osc, oem, stub_material_np, p["rays_o"], p["rays_d"], p["dx_du"], p["dy_dv"], int(p["spp"]), int(p["indir_depth"]), us)
+    np.testing.assert_array_equal(L.detach().cpu().numpy(), oL)
+    # gradient: through the first bounce only (the continuation rides on the constant term), i.e. the analytic gradient of the oracle's terms
+    w = torch.rand(L.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    (gr,) = torch.autograd.grad((L * w).sum(), em.radiance)
+    ogr = oracle_mod.grad_radiance(terms, w.cpu().numpy(), p["radiance"].shape[0])
+    assert rel_l2(gr.cpu().numpy(), ogr) <= 1e-5 and int((gr.abs().sum(-1) > 0).sum()) >= 1
+    # random draws: finite, and deeper continuation only adds light
+    torch.manual_seed(0)
+    Lr = path_tracing(sc, em, StubMaterial(), *rays, 16, 3)
+    torch.manual_seed(0)
+    Lr0 = path_tracing(sc, em, StubMaterial(), *rays, 16, 0)
+    assert torch.isfinite(Lr).all() and Lr.shape == Lr0.shape and float(Lr.detach().mean()) > float(Lr0.detach().mean())

@@ -394,6 +394,32 @@ def main():
     print("refine: indirect mean", float(Li.mean()), "det_diff mean", float(Ld.mean()), "det_spec means", float(Ls0.mean()), float(Ls1.mean()),
           "draws", len(rec_i), len(rec_d), len(rec_s))
 
+    # ------------------------------------------------------------------ utils/path_tracing.py:214-318: path_tracing (render.py's integrator): the first
+    # bounce of path_tracing_single with trace_roughness 0.6 + trace_indirect for the continuation (no grad), forward + d/d radiance
+    # (forward only, as render.py runs it under no_grad: with torch >= 2 the reference's in-place `active_next[active_next.clone()] = valid_next`
+    #  (:304) invalidates the index its own `L[active_next] += ...` saved for backward)
+    #  Seed: with seed 7 one of the 517 continuing paths draws a direction 3e-4 rad below a wall it sits on; whether origin + RayEpsilon * wi
+    #  rounds to the wall plane or one ulp behind it (hit or miss) then depends on the last bit of that direction, which torch's and the
+    #  oracle's sin / cos do not share -- and from that bounce on the recorded draws belong to another path set.  Seed 8 has no such ray.)
+    torch.manual_seed(int(os.environ.get("IRIS_GOLDEN_PT_FULL_SEED", "8")))
+    with torch.no_grad():
+        Lf, rec_f = record(lambda: rpt.path_tracing(None, em_l, ref_mat, ro, rd, dxdu, dydv, spp_p, 3))
+    def replay(fn, rec):                               # the same draws again
+        it = iter(rec)
+        torch.rand = lambda *a, **k: next(it).clone()
+        try:
+            return fn()
+        finally:
+            torch.rand = real_rand
+    with torch.no_grad():
+        Lf0 = replay(lambda: rpt.path_tracing(None, em_l, ref_mat, ro, rd, dxdu, dydv, spp_p, 0), rec_f[:5])      # first bounce alone (indir_depth 0)
+    full = {"rays_o": ro.numpy(), "rays_d": rd.numpy(), "dx_du": dxdu.numpy(), "dy_dv": dydv.numpy(), "spp": spp_p, "indir_depth": 3, "n_u": len(rec_f),
+            "L": Lf.detach().numpy(), "L_first_bounce": Lf0.numpy(), "radiance": em_l.radiance.detach().numpy(), "emitter_vertices": bev_real.numpy(), "emitter_cdf": em_l.emitter_cdf.numpy()}
+    for k, t in enumerate(rec_f):
+        full[f"u_{k}"] = t.numpy()
+    np.savez(os.path.join(OUT, "pt_full.npz"), **full)
+    print("pt_full: L mean", float(Lf.mean()), "draws", len(rec_f), [tuple(r.shape) for r in rec_f[:6]])
+
     # ------------------------------------------------------------------ 8(f)-2: VoxelSLF.scatter_add (mean-pooling builder of slf_bake.py:120-138)
     torch.manual_seed(6)
     Hq = 16
