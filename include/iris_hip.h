@@ -143,6 +143,16 @@ IRIS_API int iris_bake_view(const iris_scene *, const iris_emitter *, const iris
 /* ---- a10: lerp_specular (utils/ops.py:99-118): specular (B,R,3), roughness (B) -> (B,3) ------------------ */
 IRIS_API int iris_lerp_specular(const float *specular, const float *roughness, int64_t B, int R, float *out, iris_stream_t);
 
+/* ---- a3 / a4 helpers (utils/ops.py:12-96) as calls of their own; the bake and path-tracing kernels use the same device functions fused.
+ * get_normal_space: normal (B,3) -> (B,3,3), columns tangent, bitangent, normal.  double_sided: N (B,3) flipped in place towards V.
+ * angle2xyz: theta, phi (B) -> unit (B,3).  ggx_terms, element-wise over B (the caller broadcasts):
+ *   op 0 D_GGX(a = cos_h, b = roughness)   1 G1_GGX_Schlick(a = NoV, b = roughness)   2 G_Smith(a = NoV, b = NoL, c = roughness)
+ *   op 3 fresnelSchlick(a = VoH, b = F0)   4 fresnelSchlick_sep(a = VoH) -> out = 1 - x, out2 = x with x = (1 - VoH)^5 */
+IRIS_API int iris_get_normal_space(const float *normal, int64_t B, float *out, iris_stream_t);
+IRIS_API int iris_double_sided(const float *V, float *N, int64_t B, iris_stream_t);
+IRIS_API int iris_angle2xyz(const float *theta, const float *phi, int64_t B, float *out, iris_stream_t);
+IRIS_API int iris_ggx_terms(int op, const float *a, const float *b, const float *c, int64_t B, float *out, float *out2, iris_stream_t);
+
 /* ---- a9 (BASELINE cfg 5): path_tracing_single (utils/path_tracing.py:320-407) ------------------------------ */
 /* Building blocks of the call surface: */
 /* SLFEmitter.sample_emitter (model/emitter.py:224-255): s1 (N), s2 (N,2), position (N,3) -> wi (N,3), pdf (N), tri (N) */

@@ -546,6 +546,74 @@ extern "C" IRIS_API int iris_lerp_specular(const float* specular, const float* r
     return IRIS_OK;
 }
 
+// ---- the small helpers of utils/ops.py as calls of their own (inside the bake / path-tracing kernels the same device functions are fused)
+__global__ void normal_space_kernel(const float* normal, int64_t B, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const f3 n = ld3(normal + i * 3);
+        f3 t, b;
+        normal_space(n, t, b);
+        float* o = out + i * 9;                    // (B,3,3)[i][row][col], columns tangent, bitangent, normal
+        o[0] = t.x; o[1] = b.x; o[2] = n.x; o[3] = t.y; o[4] = b.y; o[5] = n.y; o[6] = t.z; o[7] = b.z; o[8] = n.z;
+    }
+}
+__global__ void double_sided_kernel(const float* V, float* N, int64_t B) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const f3 v = ld3(V + i * 3), n = ld3(N + i * 3);
+        if (t_dot(n, v) < 0.f) st3(N + i * 3, mk3(-n.x, -n.y, -n.z));
+    }
+}
+__global__ void angle2xyz_kernel(const float* theta, const float* phi, int64_t B, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const float st = sinf(theta[i]), ct = cosf(theta[i]), sp = sinf(phi[i]), cp = cosf(phi[i]);
+        st3(out + i * 3, t_normalize(mk3(st * cp, st * sp, ct)));
+    }
+}
+// op 0: D_GGX(a = cos_h, b = eta)   1: G1_GGX_Schlick(a = NoV, b = eta)   2: G_Smith(a = NoV, b = NoL, c = eta)
+//    3: fresnelSchlick(a = VoH, b = F0)   4: fresnelSchlick_sep(a = VoH) -> out = 1 - x, out2 = x      (x = (1 - VoH)^5)
+__global__ void ggx_terms_kernel(int op, const float* a, const float* b, const float* c, int64_t B, float* out, float* out2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = a[i];
+        if (op == 0) out[i] = D_GGX(x, b[i]);
+        else if (op == 1) out[i] = G1_GGX_Schlick(x, b[i]);
+        else if (op == 2) out[i] = G1_GGX_Schlick(b[i], c[i]) * G1_GGX_Schlick(x, c[i]);
+        else {
+            const float y = 1.f - x, y2 = y * y, p5 = y2 * y2 * y;
+            if (op == 3) out[i] = b[i] + (1.f - b[i]) * p5;
+            else { out[i] = 1.f - p5; out2[i] = p5; }
+        }
+    }
+}
+extern "C" IRIS_API int iris_get_normal_space(const float* normal, int64_t B, float* out, iris_stream_t stream) {
+    if (B < 0 || (B > 0 && (!normal || !out))) return fail(IRIS_ERR_ARG, "iris_get_normal_space: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(normal_space_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, normal, B, out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_double_sided(const float* V, float* N, int64_t B, iris_stream_t stream) {
+    if (B < 0 || (B > 0 && (!V || !N))) return fail(IRIS_ERR_ARG, "iris_double_sided: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(double_sided_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, V, N, B);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_angle2xyz(const float* theta, const float* phi, int64_t B, float* out, iris_stream_t stream) {
+    if (B < 0 || (B > 0 && (!theta || !phi || !out))) return fail(IRIS_ERR_ARG, "iris_angle2xyz: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(angle2xyz_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, phi, B, out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_ggx_terms(int op, const float* a, const float* b, const float* c, int64_t B, float* out, float* out2, iris_stream_t stream) {
+    const bool need_b = op != 4, need_c = op == 2, need_2 = op == 4;
+    if (op < 0 || op > 4 || B < 0 || (B > 0 && (!a || !out || (need_b && !b) || (need_c && !c) || (need_2 && !out2))))
+        return fail(IRIS_ERR_ARG, "iris_ggx_terms: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(ggx_terms_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, op, a, b, c, B, out, out2);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 // ---- 8(f)-3: packed shading cache + shading combine (iris_cache.h)
 extern "C" IRIS_API int iris_cache_row_floats(int R) { return (R < 1 || R > kMaxLevels) ? 0 : cache_row_floats(R); }
 extern "C" IRIS_API int iris_cache_pack(const float* diffuse, const float* const* spec0, const float* const* spec1, int64_t n, int R, float* rows,

@@ -1,0 +1,60 @@
+"""utils/ops.py's small helpers as HIP calls (SURVEY.md section 8 a3 / a4 "helpers"): get_normal_space, angle2xyz, double_sided against the
+reference's own outputs (tests/golden/frame.npz) and the oracle; the GGX / Fresnel terms against their formulas evaluated in f32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frame_angle_double_sided(oracle_mod):
+    from iris_amd.utils import ops
+    dev = torch.device("cuda:0")
+    g = golden("frame.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f = ops.get_normal_space(T(g["normal"]))
+    assert f.shape == g["frames"].shape
+    np.testing.assert_allclose(f.cpu().numpy(), g["frames"], atol=1e-6, rtol=0)                    # vs the reference
+    np.testing.assert_array_equal(f.cpu().numpy(), oracle_mod.get_normal_space(g["normal"]))         # vs the oracle, bit for bit
+    assert ops.get_normal_space(T(g["normal"]).reshape(13, -1, 3)).shape == (13, g["normal"].shape[0] // 13, 3, 3)
+    xyz = ops.angle2xyz(T(g["theta"]), T(g["phi"]))
+    np.testing.assert_allclose(xyz.cpu().numpy(), g["xyz"], atol=1e-6, rtol=0)
+    N = T(g["N"]).clone()
+    out = ops.double_sided(T(g["V"]), N)
+    assert out.data_ptr() == N.data_ptr()                                                          # in place, as the reference
+    np.testing.assert_array_equal(N.cpu().numpy(), g["N_flipped"])
+    Nt = T(g["N"]).t().contiguous().t()                                                            # a non-contiguous view is updated too
+    ops.double_sided(T(g["V"]), Nt)
+    np.testing.assert_array_equal(Nt.cpu().numpy(), g["N_flipped"])
+    assert ops.get_normal_space(torch.empty(0, 3, device=dev)).shape == (0, 3, 3)
+
+
+def test_ggx_and_fresnel_terms():
+    from iris_amd.utils import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    n = 4096
+    c = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32); l = rng.random(n).astype(np.float32)
+    eta = (0.02 + 0.98 * rng.random(n)).astype(np.float32); f0 = rng.random(n).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    f32 = np.float32
+    a2 = (eta * eta) * (eta * eta)
+    den = c * c * (a2 - f32(1)) + f32(1)
+    np.testing.assert_allclose(ops.D_GGX(T(c), T(eta)).cpu().numpy(), a2 / (f32(np.pi) * den * den), rtol=2e-6)
+    k = (eta + f32(1)) * (eta + f32(1)) / f32(8)
+    g1 = lambda x: f32(1) / (x * (f32(1) - k) + k)
+    np.testing.assert_allclose(ops.G1_GGX_Schlick(T(v), T(eta)).cpu().numpy(), g1(v), rtol=2e-6)
+    np.testing.assert_allclose(ops.G_Smith(T(v), T(l), T(eta)).cpu().numpy(), g1(l) * g1(v), rtol=4e-6)
+    x = (f32(1) - v) ** 5
+    np.testing.assert_allclose(ops.fresnelSchlick(T(v), T(f0)).cpu().numpy(), f0 + (f32(1) - f0) * x, rtol=2e-6, atol=1e-7)
+    s0, s1 = ops.fresnelSchlick_sep(T(v))
+    np.testing.assert_allclose(s0.cpu().numpy(), f32(1) - x, rtol=2e-6, atol=1e-7); np.testing.assert_allclose(s1.cpu().numpy(), x, rtol=4e-6, atol=1e-9)
+    # broadcasting as the torch formulas of the reference allow: (B,1) against a scalar roughness, (B,1) VoH against (B,3) F0
+    d = ops.D_GGX(T(c).reshape(-1, 1), 0.3)
+    assert d.shape == (n, 1)
+    np.testing.assert_array_equal(d.reshape(-1).cpu().numpy(), ops.D_GGX(T(c), T(np.full(n, 0.3, np.float32))).cpu().numpy())
+    F = ops.fresnelSchlick(T(v).reshape(-1, 1), T(np.stack([f0, f0 * f32(0.5), f0 * f32(0.25)], 1)))
+    assert F.shape == (n, 3)
+    np.testing.assert_array_equal(F[:, 0].cpu().numpy(), ops.fresnelSchlick(T(v), T(f0)).cpu().numpy())
