@@ -103,6 +103,9 @@ IRIS_API int iris_sample_diffuse(const float *u2, const float *normal, int64_t B
                         iris_stream_t);
 IRIS_API int iris_sample_specular(const float *u2, const float *wo, const float *normal, float roughness, int64_t B, float *wi,
                          float *pdf, float *w0, float *w1, iris_stream_t);
+/* the same with one roughness per sample (model/brdf.py:36-59 specular_sampler is called with a Bx1 roughness by sample_brdf) */
+IRIS_API int iris_sample_specular_v(const float *u2, const float *wo, const float *normal, const float *roughness, int64_t B,
+                           float *wi, float *pdf, float *w0, float *w1, iris_stream_t);
 
 /* ---- a5: VoxelSLF.spatial_idx/forward (model/slf.py:41-70), SLFEmitter.eval_emitter (model/emitter.py:180-221) */
 IRIS_API int iris_slf_lookup(const iris_slf *, const float *x, int64_t B, int64_t *idx /*nullable*/, float *rgb /*nullable*/,

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "iris_intersect": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "iris_sample_diffuse": [_P, _P, _I64, _P, _P, _P, _P],
     "iris_sample_specular": [_P, _P, _P, _F, _I64, _P, _P, _P, _P, _P],
+    "iris_sample_specular_v": [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
     "iris_slf_lookup": [_P, _P, _I64, _P, _P, _P],
     "iris_eval_emitter": [_P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P],
     "iris_bake_workspace_bytes": [_I64, _I32, _I32],

@@ -465,10 +465,11 @@ extern "C" IRIS_API int iris_sample_diffuse(const float* u2, const float* normal
 }
 
 __global__ void sample_specular_kernel(const float* __restrict__ u2, const float* __restrict__ wo, const float* __restrict__ normal,
-                                       float rough, int64_t B, float* __restrict__ wi, float* __restrict__ pdf, float* __restrict__ w0,
-                                       float* __restrict__ w1) {
+                                       float rough_all, const float* __restrict__ rough_each, int64_t B, float* __restrict__ wi, float* __restrict__ pdf,
+                                       float* __restrict__ w0, float* __restrict__ w1) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
         f3 n = ld3(normal + i * 3), o = ld3(wo + i * 3), t, b;
+        const float rough = rough_each ? rough_each[i] : rough_all;
         normal_space(n, t, b);
         f3 d = specular_sampler(u2[i * 2], u2[i * 2 + 1], rough, o, n, t, b);
         SpecW w = specular_weights(d, o, n, rough, pdf != nullptr);
@@ -482,7 +483,16 @@ extern "C" IRIS_API int iris_sample_specular(const float* u2, const float* wo, c
                                     float* pdf, float* w0, float* w1, iris_stream_t stream) {
     if (B < 0 || (B > 0 && (!u2 || !wo || !normal || !wi))) return fail(IRIS_ERR_ARG, "iris_sample_specular: bad arguments");
     if (B == 0) return IRIS_OK;
-    hipLaunchKernelGGL(sample_specular_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, u2, wo, normal, roughness, B,
+    hipLaunchKernelGGL(sample_specular_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, u2, wo, normal, roughness,
+                       (const float*)nullptr, B, wi, pdf, w0, w1);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+extern "C" IRIS_API int iris_sample_specular_v(const float* u2, const float* wo, const float* normal, const float* roughness, int64_t B, float* wi,
+                                      float* pdf, float* w0, float* w1, iris_stream_t stream) {
+    if (B < 0 || (B > 0 && (!u2 || !wo || !normal || !roughness || !wi))) return fail(IRIS_ERR_ARG, "iris_sample_specular_v: bad arguments");
+    if (B == 0) return IRIS_OK;
+    hipLaunchKernelGGL(sample_specular_kernel, dim3(grid_for(B, 256, 8192)), dim3(256), 0, (hipStream_t)stream, u2, wo, normal, 0.f, roughness, B,
                        wi, pdf, w0, w1);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;

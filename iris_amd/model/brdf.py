@@ -5,6 +5,16 @@ import torch.nn as nn
 from .. import _lib as L
 
 
+def diffuse_sampler(sample2, normal):
+    """cosine-weighted direction around `normal` (model/brdf.py:20-34): the direction sample_diffuse draws"""
+    return BaseBRDF().sample_diffuse(sample2, normal)[0]
+
+
+def specular_sampler(sample2, roughness, wo, normal):
+    """GGX half-vector sample reflected about it (model/brdf.py:36-59): the direction sample_specular draws"""
+    return BaseBRDF().sample_specular(sample2, wo, normal, roughness)[0]
+
+
 class BaseBRDF(nn.Module):
     """Parameter-free BRDF used by bake_shading (bake_shading.py:79)."""
 
@@ -13,6 +23,33 @@ class BaseBRDF(nn.Module):
 
     def forward(self):
         pass
+
+    def eval_diffuse(self, wi, normal):
+        """(brdf Bx3, pdf Bx1), both relu(n.wi) / pi (model/brdf.py:70-76)"""
+        import math
+        wi = L.require_gpu(wi, torch.float32, "wi").reshape(-1, 3)
+        normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
+        pdf = ((normal * wi).sum(-1, keepdim=True)).relu() / math.pi
+        return pdf.expand(wi.shape[0], 3), pdf
+
+    def eval_specular(self, wi, wo, normal, roughness):
+        """(brdf_spec0 Bx1, brdf_spec1 Bx1, pdf Bx1): the GGX lobe split by the two Schlick terms, F = ks F0 + F1 (model/brdf.py:90-110);
+        D, G and the Fresnel terms are the HIP helpers of iris_amd.utils.ops"""
+        from ..utils import ops
+        wi = L.require_gpu(wi, torch.float32, "wi").reshape(-1, 3)
+        wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
+        normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
+        half = torch.nn.functional.normalize(wi + wo, dim=-1)
+        dot = lambda a, b: (a * b).sum(-1, keepdim=True).relu()
+        n_l, n_v, v_h, n_h = dot(wi, normal), dot(wo, normal), dot(wo, half), dot(normal, half)
+        if not torch.is_tensor(roughness):
+            roughness = torch.tensor(float(roughness), device=wi.device)
+        rough = roughness.detach().to(torch.float32).reshape(-1, 1) if roughness.numel() > 1 else roughness.detach().to(torch.float32).reshape(1, 1)
+        D = ops.D_GGX(n_h, rough)
+        pdf = D / (4 * v_h.clamp_min(1e-4)) * n_h
+        DG = D * ops.G_Smith(n_v, n_l, rough)
+        f0, f1 = ops.fresnelSchlick_sep(v_h)
+        return DG * f0 / 4.0 * n_l, DG * f1 / 4.0 * n_l, pdf
 
     def sample_diffuse(self, sample2, normal):
         """Cosine-weighted direction, pdf = relu(n.wi)/pi, weight = 1 (model/brdf.py:78-88)."""
@@ -28,21 +65,28 @@ class BaseBRDF(nn.Module):
 
     def sample_specular(self, sample2, wo, normal, roughness):
         """GGX half-vector sampling and the two Fresnel-split weights (model/brdf.py:112-136).
-        roughness: python float or 0-d tensor (bake_shading.py:161 iterates a linspace)."""
+        roughness: python float or 0-d tensor (bake_shading.py:161 iterates a linspace), or one value per sample (Bx1)."""
         sample2 = L.require_gpu(sample2, torch.float32, "sample2").reshape(-1, 2)
         wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
         normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
-        if isinstance(roughness, torch.Tensor):
-            if roughness.numel() != 1:
-                raise L.IrisError("sample_specular: per-sample roughness is not on the bake path; pass a scalar")
-            roughness = float(roughness.detach().float().cpu().item())
         B = sample2.shape[0]
+        each = None
+        if isinstance(roughness, torch.Tensor):
+            if roughness.numel() == 1:
+                roughness = float(roughness.detach().float().cpu().item())
+            else:                                           # one roughness per sample (what sample_brdf hands to specular_sampler)
+                each = L.require_gpu(roughness.detach(), torch.float32, "roughness").reshape(-1)
+                if each.shape[0] != B:
+                    raise L.IrisError(f"sample_specular: {each.shape[0]} roughness values for {B} samples")
         wi = torch.empty(B, 3, device=sample2.device, dtype=torch.float32)
         pdf = torch.empty(B, 1, device=sample2.device, dtype=torch.float32)
         w0 = torch.empty(B, 1, device=sample2.device, dtype=torch.float32)
         w1 = torch.empty(B, 1, device=sample2.device, dtype=torch.float32)
         with torch.cuda.device(sample2.device):
-            L.check(L.lib().iris_sample_specular(L.ptr(sample2), L.ptr(wo), L.ptr(normal), roughness, B, L.ptr(wi), L.ptr(pdf), L.ptr(w0), L.ptr(w1), L.stream()))
+            if each is not None:
+                L.check(L.lib().iris_sample_specular_v(L.ptr(sample2), L.ptr(wo), L.ptr(normal), L.ptr(each), B, L.ptr(wi), L.ptr(pdf), L.ptr(w0), L.ptr(w1), L.stream()))
+            else:
+                L.check(L.lib().iris_sample_specular(L.ptr(sample2), L.ptr(wo), L.ptr(normal), roughness, B, L.ptr(wi), L.ptr(pdf), L.ptr(w0), L.ptr(w1), L.stream()))
         return wi, pdf, w0, w1
 
     @staticmethod

@@ -58,3 +58,35 @@ def test_ggx_and_fresnel_terms():
     F = ops.fresnelSchlick(T(v).reshape(-1, 1), T(np.stack([f0, f0 * f32(0.5), f0 * f32(0.25)], 1)))
     assert F.shape == (n, 3)
     np.testing.assert_array_equal(F[:, 0].cpu().numpy(), ops.fresnelSchlick(T(v), T(f0)).cpu().numpy())
+
+
+def test_eval_diffuse_specular_compose_to_eval_brdf():
+    """BaseBRDF.eval_diffuse / eval_specular (model/brdf.py:70-110) and the module-level samplers: kd diffuse + ks spec0 + spec1 is eval_brdf,
+    whose values the reference pinned (tests/golden/pt_units.npz)."""
+    from iris_amd.model.brdf import BaseBRDF, diffuse_sampler, specular_sampler
+    dev = torch.device("cuda:0")
+    u = golden("pt_units.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    wi, wo, n = T(u["wi"]), T(u["wo"]), T(u["normal"])
+    albedo, rough, metal = T(u["albedo"]), T(u["roughness"]), T(u["metallic"])
+    b = BaseBRDF()
+    bd, pd = b.eval_diffuse(wi, n)
+    s0, s1, ps = b.eval_specular(wi, wo, n, rough)
+    kd, ks = albedo * (1 - metal), 0.04 * (1 - metal) + albedo * metal
+    brdf, pdf = kd * bd + ks * s0 + s1, 0.5 * ps + 0.5 * pd
+    rel = lambda a, r: float(np.linalg.norm(a.cpu().numpy().astype(np.float64) - r) / np.linalg.norm(r))
+    # (D_GGX's denominator cancels for the peaked lobes among these materials: values up to 9e4 carry the rounding of a different operation order)
+    assert rel(brdf, u["brdf"]) <= 5e-5 and rel(pdf, u["brdf_pdf"]) <= 5e-5
+    g = golden("sample_diffuse.npz")
+    np.testing.assert_array_equal(diffuse_sampler(T(g["u2"]), T(g["normal"])).cpu().numpy(), b.sample_diffuse(T(g["u2"]), T(g["normal"]))[0].cpu().numpy())
+    np.testing.assert_allclose(diffuse_sampler(T(g["u2"]), T(g["normal"])).cpu().numpy(), g["wi"], atol=2e-6, rtol=0)
+    # one roughness per sample (what sample_brdf hands to specular_sampler): row by row the scalar-roughness result
+    B = wo.shape[0]
+    u2 = torch.rand(B, 2, device=dev)
+    r = torch.where(torch.arange(B, device=dev) % 2 == 0, 0.3, 0.7).reshape(B, 1)
+    got = b.sample_specular(u2, wo, n, r)
+    for val, rows in ((0.3, slice(0, None, 2)), (0.7, slice(1, None, 2))):
+        ref = b.sample_specular(u2, wo, n, val)
+        for a, c in zip(got, ref):
+            np.testing.assert_array_equal(a[rows].cpu().numpy(), c[rows].cpu().numpy())
+    np.testing.assert_array_equal(specular_sampler(u2, r, wo, n).cpu().numpy(), got[0].cpu().numpy())
