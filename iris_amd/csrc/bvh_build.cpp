@@ -58,17 +58,26 @@ struct Builder {
 
         int best_axis = -1, best_bin = -1;
         float best_cost = kInf;
+        // one pass over the triangles fills the bins of all three axes (the gather tri[order[i]] is what a large node pays for)
+        Box bins[3][kBins]; int cnt[3][kBins];
+        float scale3[3]; bool use[3];
         for (int ax = 0; ax < 3; ++ax) {
-            float ext = cb.hi[ax] - cb.lo[ax];
-            if (!(ext > 0.f)) continue;
-            Box bb[kBins]; int bc[kBins];
-            for (int k = 0; k < kBins; ++k) { bb[k].reset(); bc[k] = 0; }
-            const float scale = (float)kBins / ext;
-            for (int32_t i = start; i < start + count; ++i) {
-                const TriInfo& t = tri[order[i]];
-                int k = std::min(kBins - 1, std::max(0, (int)((t.c[ax] - cb.lo[ax]) * scale)));
-                bb[k].grow(t.b); bc[k]++;
+            const float ext = cb.hi[ax] - cb.lo[ax];
+            use[ax] = ext > 0.f;
+            scale3[ax] = use[ax] ? (float)kBins / ext : 0.f;
+            for (int k = 0; k < kBins; ++k) { bins[ax][k].reset(); cnt[ax][k] = 0; }
+        }
+        for (int32_t i = start; i < start + count; ++i) {
+            const TriInfo& t = tri[order[i]];
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!use[ax]) continue;
+                const int k = std::min(kBins - 1, std::max(0, (int)((t.c[ax] - cb.lo[ax]) * scale3[ax])));
+                bins[ax][k].grow(t.b); cnt[ax][k]++;
             }
+        }
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!use[ax]) continue;
+            const Box* bb = bins[ax]; const int* bc = cnt[ax];
             float ra[kBins]; int rc[kBins];
             Box acc; acc.reset(); int n = 0;
             for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); n += bc[k]; ra[k] = acc.area(); rc[k] = n; }

@@ -78,9 +78,10 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 
     f3 qvec = x_cross(tvec, e1);
     float v = x_dot(d, qvec) * inv_det;
     float t = x_dot(e2, qvec) * inv_det;
-    bool ok = u >= 0.f && v >= 0.f && (u + v) <= 1.f && t >= 0.f && t < INFINITY;
-    // closest hit = lexicographic min of (t, original index)
-    if (ok && (t < h.t || (t == h.t && id < h.id) || h.slot < 0)) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
+    // u >= 0 && v >= 0 && t >= 0 as one three-way minimum: a NaN operand is skipped by fminf, and then fails (u + v) <= 1 or t < inf below
+    bool ok = fminf(fminf(u, v), t) >= 0.f && (u + v) <= 1.f && t < INFINITY;
+    // closest hit = lexicographic min of (t, original index); the first hit passes t < h.t because h.t starts at +inf and t is finite
+    if (ok && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
 }
 
 // -------------------------------------------------------------------------------------------------------
