@@ -281,6 +281,61 @@ static void run_lds(int cus, int n_rec, int group_shift, int blocks_per_cu, uint
     fflush(stdout);
 }
 
+// ------------------------------------------------------------------------------------------------ counter calibration (round 3)
+// One process = one known workload, so that a `rocprofv3 --pmc ... -- tools/microbench/mb calib <what>` run can be compared with ground truth:
+//   calib fma | mix | blend | max | rcp : the valu kernel of that class, 7 waves/SIMD, 4096 x 32 instructions per wave -> what SQ_INSTS_VALU,
+//                                   SQ_ACTIVE_INST_VALU and SQ_ACTIVE_INST_VALU2 read for a pure dual-issue class, a pure 4-cycle class and the mix
+//   calib gather | gather1        : lane-divergent random 64-B records of a 1 GiB table (4 x 16 B / 1 x 16 B per record): known bytes requested
+//   calib stream                  : every lane reads consecutive 16 B (wave = 1 KiB contiguous), 1 GiB once: the guide's 1/2-counting case
+// Prints the ground truth (instructions / bytes of the timed dispatch) as JSON; tools/calib_summary.py joins it with the counter CSVs.
+__global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ table, size_t n16, uint32_t* out) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = table[i];
+        acc ^= (v.x ^ v.y) ^ (v.z ^ v.w);
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int OP>
+static void calib_valu(int cus, float* d_out, unsigned long long* d_cyc, unsigned long long* d_real) {
+    const int w = 7, iters = 4096, blocks = cus * w, n_waves = blocks * 4;
+    run_valu<OP>(cus, w, d_out, d_cyc, d_real);     // dispatch 1 = 64-trip warm-up, dispatch 2 = the measured one
+    printf("{\"bench\": \"calib\", \"what\": \"valu\", \"op\": \"%s\", \"waves\": %d, \"loop_wave_insts\": %.0f, \"dispatch\": 2}\n", kOpName[OP], n_waves,
+           (double)iters * 32.0 * n_waves);
+}
+
+static void calib_mem(const char* what, int cus, uint32_t* d_out, unsigned long long* d_cyc) {
+    const size_t bytes = 1ull << 30;
+    uint4* d_table;
+    CHECK(hipMalloc(&d_table, bytes));
+    CHECK(hipMemset(d_table, 0x5a, bytes));
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float ms = 0.f;
+    if (!strcmp(what, "stream")) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(stream_kernel, dim3(cus * 8), dim3(256), 0, 0, d_table, bytes / 16, d_out);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("{\"bench\": \"calib\", \"what\": \"stream\", \"bytes_requested\": %zu, \"kernel_ms\": %.3f, \"TBps\": %.3f, \"dispatch\": 1}\n", bytes, ms,
+               bytes / (ms * 1e-3) / 1e12);
+    } else {
+        const int loads = !strcmp(what, "gather1") ? 1 : 4;
+        GatherCfg g{"HBM1G", bytes, loads, 0, ~0ull, false, 7};
+        const int iters = 1024, blocks = cus * g.waves_per_simd, n_waves = blocks * 4;
+        if (loads == 1) launch_gather<1, false>(g, cus, d_table, d_out, d_cyc, iters, &ms);
+        else launch_gather<4, false>(g, cus, d_table, d_out, d_cyc, iters, &ms);
+        const double records = (double)n_waves * 64.0 * iters * 4.0;     // U = 4 independent records per trip
+        printf("{\"bench\": \"calib\", \"what\": \"%s\", \"records\": %.0f, \"bytes_requested\": %.0f, \"bytes_of_lines_touched_64B\": %.0f, "
+               "\"bytes_of_lines_touched_128B\": %.0f, \"kernel_ms\": %.3f, \"dispatch\": 2, \"note\": \"dispatch 1 is the same kernel with iters/4\"}\n",
+               what, records, records * 16.0 * loads, records * 64.0, records * 128.0, ms);
+    }
+    CHECK(hipFree(d_table));
+}
+
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     const bool all = !strcmp(what, "all");
@@ -292,6 +347,16 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&d_out, 4096));
     CHECK(hipMalloc(&d_cyc, 8 * cus * 8 * 4 * 2));
     CHECK(hipMalloc(&d_real, 8 * cus * 8 * 4 * 2));
+    if (!strcmp(what, "calib")) {
+        const char* sub = argc > 2 ? argv[2] : "fma";
+        if (!strcmp(sub, "fma")) calib_valu<OP_FMA>(cus, d_out, d_cyc, d_real);
+        else if (!strcmp(sub, "mix")) calib_valu<OP_FMA_MIX>(cus, d_out, d_cyc, d_real);
+        else if (!strcmp(sub, "blend")) calib_valu<OP_CMP_NOP_CND>(cus, d_out, d_cyc, d_real);
+        else if (!strcmp(sub, "max")) calib_valu<OP_MAX>(cus, d_out, d_cyc, d_real);
+        else if (!strcmp(sub, "rcp")) calib_valu<OP_RCP>(cus, d_out, d_cyc, d_real);
+        else calib_mem(sub, cus, (uint32_t*)d_out, d_cyc);
+        return 0;
+    }
 
     if (all || !strcmp(what, "valu")) {
         for (int w : {2, 7}) {
