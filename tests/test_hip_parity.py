@@ -375,9 +375,14 @@ def test_bake_diffuse_vs_oracle(dev, oracle_mod, room_setup, spp):
     np.testing.assert_array_equal(N(Ld), oLd)
     assert (otri >= 0).all()
     # literal (libm) oracle: agreement is statistical because the SLF / emitter lookups are discontinuous
-    lLd, ltri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=11, stream=0, pix_id=pix, want_tri=True)
-    assert (N(tri) == ltri).mean() >= 0.9995
-    assert rel_l2(N(Ld), lLd) <= 1e-3
+    # (north_star's 1e-4 against the reference's own Python is measured per map in tests/test_parity_room.py; here: rounding only once the
+    # pixels holding a flipped sample are set aside, and no more than 2.5e-5 of the samples flipped)
+    lLd, ltri, lsrc = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=11, stream=0, pix_id=pix, want_tri=True, want_src=True)
+    _, _, src = bs.bake_diffuse(s["sc"], s["em"], T(pos, dev), T(nrm, dev), spp, seed=11, stream_id=0, pix_id=T(pix, dev), want_tri=True, want_src=True)
+    flip = (N(tri) != ltri) | (N(src) != lsrc)          # a flip: another triangle, or another row of the radiance tables
+    keep = ~flip.reshape(P, spp).any(1)
+    assert flip.mean() <= 5e-5
+    assert rel_l2(N(Ld)[keep], lLd[keep]) <= 1e-6
 
 
 @pytest.mark.parametrize("r_idx", [0, 2, 5])
@@ -394,8 +399,12 @@ def test_bake_specular_vs_oracle(dev, oracle_mod, room_setup, r_idx):
     np.testing.assert_array_equal(N(Ls0), o0)
     np.testing.assert_array_equal(N(Ls1), o1)
     l0, l1, ltri = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=rough, seed=5, stream=1 + r_idx, want_tri=True)
-    assert (N(tri) == ltri).mean() >= 0.999
-    assert rel_l2(N(Ls0), l0) <= 1e-3 and rel_l2(N(Ls1), l1) <= 1e-3
+    _, _, _, src = bs.bake_specular(s["sc"], s["em"], T(pos, dev), T(nrm, dev), T(wo, dev), rough, spp, seed=5, stream_id=1 + r_idx, want_tri=True, want_src=True)
+    *_, lsrc = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=rough, seed=5, stream=1 + r_idx, want_tri=True, want_src=True)
+    flip = (N(tri) != ltri) | (N(src) != lsrc)
+    keep = ~flip.reshape(P, spp).any(1)
+    assert flip.mean() <= 5e-5
+    assert rel_l2(N(Ls0)[keep], l0[keep]) <= 1e-6 and rel_l2(N(Ls1)[keep], l1[keep]) <= 1e-6
 
 
 def test_bake_cfg2_size_bit_exact_vs_oracle(dev, oracle_mod, room_setup):
