@@ -254,9 +254,9 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
                 int64_t tri = -1;
                 if (h.slot >= 0) {
                     const float4* tr = a.sc.tris + (int64_t)h.slot * 4;
-                    const float4 ta = tr[0], tc = tr[2], te = tr[3];
-                    pn = hit_position(h, mk3(ta.x, ta.y, ta.z), mk3(tc.z, tc.w, te.x), mk3(te.y, te.z, te.w));
-                    tri = __float_as_int(tc.y);
+                    const float4 tx = tr[0], ty = tr[1], tz = tr[2];      // component-major record (iris_trace.h)
+                    pn = hit_position(h, mk3(tx.x, ty.x, tz.x), mk3(tx.y, ty.y, tz.y), mk3(tx.z, ty.z, tz.z));
+                    tri = __float_as_int(tx.w);
                 }
                 if (a.tri_next) a.tri_next[(p0 + pl) * spp + s] = tri;
                 float epdf; bool vn; int src;

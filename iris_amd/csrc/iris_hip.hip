@@ -188,22 +188,19 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
             for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }
     }
-    // ---- encode leaf triangles (64 B, one per 64-B line): p0, e1 = p1 - p0, e2 = p2 - p0 (f32 subtractions, exactly what the
-    // Moeller-Trumbore contract computes), original index, then p1, p2 for the hit point ----
+    // ---- encode leaf triangles (64 B, one per 64-B line), component-major so that the watertight test's axis permutation is an address
+    // offset: (p0.x, p1.x, p2.x, id) (p0.y, p1.y, p2.y, id) (p0.z, p1.z, p2.z, id) (0, 0, 0, 0) ----
     const size_t nt = bvh.tri_order.size();
-    std::vector<float> tris((nt + 1) * 16, 0.f);      // + the degenerate record unused child slots point to (id -1)
-    { const int32_t none = -1; std::memcpy(&tris[nt * 16 + 9], &none, 4); }
+    std::vector<float> tris((nt + 1) * 16, 0.f);      // + the degenerate record unused child slots point to (id -1, never accepted: det = 0)
+    { const int32_t none = -1; for (int k = 0; k < 3; ++k) std::memcpy(&tris[nt * 16 + 4 * k + 3], &none, 4); }
     for (size_t i = 0; i < nt; ++i) {
         int32_t f = bvh.tri_order[i];
         float* p = tris.data() + i * 16;
-        const float* v0 = verts + (int64_t)faces[(int64_t)f * 3 + 0] * 3;
-        const float* v1 = verts + (int64_t)faces[(int64_t)f * 3 + 1] * 3;
-        const float* v2 = verts + (int64_t)faces[(int64_t)f * 3 + 2] * 3;
-        for (int k = 0; k < 3; ++k) {
-            volatile float e1 = v1[k] - v0[k], e2 = v2[k] - v0[k];   // plain f32 (no excess precision, no contraction)
-            p[k] = v0[k]; p[3 + k] = e1; p[6 + k] = e2; p[10 + k] = v1[k]; p[13 + k] = v2[k];
+        for (int v = 0; v < 3; ++v) {
+            const float* pv = verts + (int64_t)faces[(int64_t)f * 3 + v] * 3;
+            for (int k = 0; k < 3; ++k) p[4 * k + v] = pv[k];
         }
-        std::memcpy(&p[9], &f, 4);
+        for (int k = 0; k < 3; ++k) std::memcpy(&p[4 * k + 3], &f, 4);
     }
     iris_scene* s = new iris_scene();
     s->device = device;

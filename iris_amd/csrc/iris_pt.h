@@ -114,9 +114,9 @@ __device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
 // hit triangle of a leaf slot: vertices + original triangle index
 __device__ __forceinline__ void hit_triangle(const SceneDev& sc, int slot, f3& p0, f3& p1, f3& p2, int& id) {
     const float4* r = sc.tris + (int64_t)slot * 4;
-    const float4 a = r[0], c = r[2], e = r[3];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(c.z, c.w, e.x); p2 = mk3(e.y, e.z, e.w);
-    id = __float_as_int(c.y);
+    const float4 X = r[0], Y = r[1], Z = r[2];      // component-major record (iris_trace.h)
+    p0 = mk3(X.x, Y.x, Z.x); p1 = mk3(X.y, Y.y, Z.y); p2 = mk3(X.z, Y.z, Z.z);
+    id = __float_as_int(X.w);
 }
 
 // utils/path_tracing.py:357-382: emitter sampling, visibility ray, geometry term, eval_brdf, power-2 MIS.

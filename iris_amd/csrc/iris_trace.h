@@ -1,4 +1,4 @@
-// BVH traversal + Moeller-Trumbore closest hit (replaces utils/path_tracing.py:30-43, the Mitsuba/OptiX call).
+// BVH traversal + watertight ray / triangle closest hit (replaces utils/path_tracing.py:30-43, the Mitsuba/OptiX call).
 // One ray per lane, per-lane traversal stack in LDS (stack[k*BLOCK + tid] -> conflict-free for ds_read/write_b32).
 #pragma once
 #include "iris_device.h"
@@ -14,7 +14,7 @@ constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
 // Scene as laid out in HBM
 struct SceneDev {
     const float4* nodes;  // layout-dependent; BVH4_F32: 8 x float4 = 128 B per node, 128-B aligned
-    const float4* tris;   // 4 x float4 = 64 B per leaf triangle: (p0.xyz,e1.x) (e1.yz,e2.xy) (e2.z,id,p1.xy) (p1.z,p2.xyz), e_k = p_k - p0
+    const float4* tris;   // 64 B per leaf triangle (one L2 half-line), component-major: (p0.x,p1.x,p2.x,id) (p0.y,p1.y,p2.y,id) (p0.z,p1.z,p2.z,id) (0,0,0,0)
     int n_nodes;
     int n_tris;
     int phase_min;  // wave-level phase scheduling threshold (see trace_bvh4)
@@ -62,25 +62,59 @@ struct Stack {
     }
 };
 
-// Moeller-Trumbore on leaf record `slot`; arithmetic contract of oracle/iris_oracle.c (explicit fmaf only).
-__device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, f3 o, f3 d, Hit& h) {
-    // 64-B record: (p0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, id, p1.xy) (p1.z, p2.xyz); the edges e1 = p1 - p0, e2 = p2 - p0 were computed by the
-    // host in f32 (the same IEEE subtraction the oracle performs), so the test needs only the first 40 bytes and no subtractions
-    const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (size_t)((uint32_t)slot << 6));   // 32-bit offset
-    float4 a = r[0], b = r[1], c = r[2];
-    f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
-    int id = __float_as_int(c.y);
-    f3 pvec = x_cross(d, e2);
-    float det = x_dot(e1, pvec);
-    float inv_det = 1.0f / det;
-    f3 tvec = sub3(o, p0);
-    float u = x_dot(tvec, pvec) * inv_det;
-    f3 qvec = x_cross(tvec, e1);
-    float v = x_dot(d, qvec) * inv_det;
-    float t = x_dot(e2, qvec) * inv_det;
-    // u >= 0 && v >= 0 && t >= 0 as one three-way minimum: a NaN operand is skipped by fminf, and then fails (u + v) <= 1 or t < inf below
-    bool ok = fminf(fminf(u, v), t) >= 0.f && (u + v) <= 1.f && t < INFINITY;
-    // closest hit = lexicographic min of (t, original index); the first hit passes t < h.t because h.t starts at +inf and t is finite
+// Watertight ray / triangle test (Woop, Benthin, Wald 2013, "Watertight Ray/Triangle Intersection", JCGT 2(1), section 3): the ray is
+// made the z axis of a sheared, axis-permuted space -- kz = the axis of d's largest magnitude, (kx, ky) the two after it, S = (d[kx], d[ky], 1) / d[kz]
+// --, every vertex is translated by the origin and sheared by the same function of (vertex, ray) in whichever triangle it appears, and the
+// three 2-D edge functions are evaluated with plain products and a plain difference: rnd(a*b) - rnd(c*d) is exactly antisymmetric in the two
+// vertices (the two triangles sharing an edge see opposite values) and never has the opposite sign of the exact value; a value of 0 is
+// re-evaluated in double (exact sign).  So no ray can slip between two triangles that share an edge or a vertex.
+// The axis permutation costs nothing here: a leaf record stores the triangle component-major -- (p0.x,p1.x,p2.x,id) (p0.y,..) (p0.z,..) -- and a
+// lane reads plane kx / ky / kz by ADDRESS (three 16-B loads from one 64-B line either way).  Arithmetic contract of oracle/iris_oracle.c.
+struct RayXf {
+    float ox, oy, oz;   // origin, permuted: o[kx], o[ky], o[kz]
+    float sx, sy, sz;   // shear: d[kx] * sz, d[ky] * sz, sz = 1 / d[kz]
+    uint32_t offx, offy, offz;   // byte offsets of planes kx, ky, kz inside a leaf record
+};
+__device__ __forceinline__ uint32_t ray_kz(f3 d) {
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    return (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+}
+__device__ __forceinline__ float pick3(f3 v, uint32_t k) { return k == 0u ? v.x : (k == 1u ? v.y : v.z); }
+__device__ __forceinline__ void ray_xform(f3 o, f3 d, RayXf& x) {
+    const uint32_t kz = ray_kz(d), kx = kz == 2u ? 0u : kz + 1u, ky = kx == 2u ? 0u : kx + 1u;
+    x.sz = 1.0f / pick3(d, kz);
+    x.sx = pick3(d, kx) * x.sz; x.sy = pick3(d, ky) * x.sz;
+    x.ox = pick3(o, kx); x.oy = pick3(o, ky); x.oz = pick3(o, kz);
+    x.offx = kx << 4; x.offy = ky << 4; x.offz = kz << 4;
+}
+
+// The test on leaf record `slot`.  Accept iff the edge functions have no two strictly opposite signs, det = U + V + W != 0 and 0 <= t < inf;
+// (b1, b2) = (V, W) / det (p = b0 p0 + b1 p1 + b2 p2), t = (U Az + V Bz + W Cz) * sz / det (z = P[kz] - o[kz]).
+__device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const RayXf& x, Hit& h) {
+    const uint32_t base = (uint32_t)slot << 6;     // 32-bit byte offset from the (scalar) table base
+    const char* tb = reinterpret_cast<const char*>(sc.tris);
+    const float4 X = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offx));
+    const float4 Y = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offy));
+    const float4 Z = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offz));
+    const int id = __float_as_int(Z.w);            // (every plane carries the index)
+    const float Atz = Z.x - x.oz, Btz = Z.y - x.oz, Ctz = Z.z - x.oz;
+    const float Ax = fmaf(-x.sx, Atz, X.x - x.ox), Ay = fmaf(-x.sy, Atz, Y.x - x.oy);
+    const float Bx = fmaf(-x.sx, Btz, X.y - x.ox), By = fmaf(-x.sy, Btz, Y.y - x.oy);
+    const float Cx = fmaf(-x.sx, Ctz, X.z - x.ox), Cy = fmaf(-x.sy, Ctz, Y.z - x.oy);
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (fminf(fminf(fabsf(U), fabsf(V)), fabsf(W)) == 0.f) {      // any of them 0 (rare: the ray through an edge or a vertex of the projected triangle, or an underflow)
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    const float det = (U + V) + W;
+    const float inv_det = 1.0f / det;
+    const float t = (fmaf(U, Atz, fmaf(V, Btz, W * Ctz)) * x.sz) * inv_det;
+    const float u = V * inv_det, v = W * inv_det;
+    // no two edge functions of strictly opposite sign; det == 0 gives t = NaN or +-inf: a NaN fails every comparison, and +inf can only tie with the
+    // initial h.t, whose h.id = INT_MIN no index is smaller than
+    const bool ok = !(fminf(fminf(U, V), W) < 0.f && fmaxf(fmaxf(U, V), W) > 0.f) && t >= 0.f;
+    // closest hit = lexicographic min of (t, original index)
     if (ok && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
 }
 
@@ -125,7 +159,9 @@ __device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >>
 
 // Per-lane traversal state shared by the two drivers below (kept in registers; the struct is scalar-replaced).
 struct RayState {
-    f3 o, d;
+    f3 o, d;                        // (scratch between fetch and prepare; the traversal itself reads the slab constants and the triangle test's transform)
+    float tox, toy, toz, sx, sy, sz;   // triangle test: permuted origin, shear (RayXf)
+    uint32_t kz;                    // its axis permutation; the three plane offsets are rebuilt from it at every leaf-phase entry
     float ix, iy, iz, nx, ny, nz;   // 1/d and -o/d
     bool px, py, pz;                // direction signs
     Hit h;
@@ -133,10 +169,11 @@ struct RayState {
 };
 __device__ __forceinline__ void ray_begin(RayState& r, f3 o, f3 d) {
     r.o = o; r.d = d;
-    r.h.t = INFINITY; r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1; r.h.id = 0x7fffffff;
+    r.h.t = INFINITY; r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1; r.h.id = (int)0x80000000;   // (INT_MIN: see tri_test)
     r.ix = safe_rcp_dir(d.x); r.iy = safe_rcp_dir(d.y); r.iz = safe_rcp_dir(d.z);
     r.nx = -(o.x * r.ix); r.ny = -(o.y * r.iy); r.nz = -(o.z * r.iz);
     r.px = r.ix >= 0.f; r.py = r.iy >= 0.f; r.pz = r.iz >= 0.f;
+    { RayXf x; ray_xform(o, d, x); r.tox = x.ox; r.toy = x.oy; r.toz = x.oz; r.sx = x.sx; r.sy = x.sy; r.sz = x.sz; r.kz = x.offz; }
     r.cur = 0;
 }
 
@@ -202,9 +239,17 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
     }
 }
 // One triangle of the current leaf.
+__device__ __forceinline__ RayXf leaf_phase_xform(const RayState& r) {
+    RayXf x;
+    x.ox = r.tox; x.oy = r.toy; x.oz = r.toz; x.sx = r.sx; x.sy = r.sy; x.sz = r.sz;
+    x.offz = r.kz;                                   // 0 / 16 / 32
+    x.offx = r.kz == 32u ? 0u : r.kz + 16u;
+    x.offy = x.offx == 32u ? 0u : x.offx + 16u;
+    return x;
+}
 template <class STACK>
-__device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, STACK& st) {
-    tri_test(sc, (int)((r.cur & 0x7fffffffu) >> 3), r.o, r.d, r.h);
+__device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, const RayXf& xf, STACK& st) {
+    tri_test(sc, (int)((r.cur & 0x7fffffffu) >> 3), xf, r.h);
     r.cur += 7u;                                                  // leaf ref = leafbit | start << 3 | count: start + 1, count - 1
     if ((r.cur & 7u) == 0u) r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
 }
@@ -231,6 +276,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
             }
         }
         // ---------------- leaf phase (one triangle per iteration)
+        const RayXf xf = leaf_phase_xform(r);
         for (;;) {
             const bool at_leaf = r.cur != kEmptyRef && (r.cur & kLeafBit);
             const int n_leaf = __popcll(__ballot(at_leaf));
@@ -238,7 +284,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
             if (n_leaf < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && !(r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (at_leaf) {
                 if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
-                leaf_step(sc, r, st);
+                leaf_step(sc, r, xf, st);
             }
         }
         if (__ballot(r.cur != kEmptyRef) == 0) break;
@@ -316,6 +362,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (pend) break;   // requested rays have had one step to arrive: go activate them
         }
         // ---------------- leaf phase
+        const RayXf xf = leaf_phase_xform(r);
         for (;;) {
             const bool at_leaf = r.cur != kEmptyRef && (r.cur & kLeafBit);
             const int n_leaf = __popcll(__ballot(at_leaf));
@@ -324,7 +371,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;
             if (at_leaf) {
                 if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
-                leaf_step(sc, r, st);
+                leaf_step(sc, r, xf, st);
             }
             if (pend) break;
         }
@@ -337,8 +384,8 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
 // n = normalize(cross(p1-p0,p2-p0)).
 __device__ __forceinline__ void hit_vertices(const SceneDev& sc, const Hit& h, f3& p0, f3& p1, f3& p2) {
     const float4* r = sc.tris + (int64_t)h.slot * 4;
-    float4 a = r[0], c = r[2], e = r[3];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(c.z, c.w, e.x); p2 = mk3(e.y, e.z, e.w);
+    float4 X = r[0], Y = r[1], Z = r[2];      // component-major: (p0.x,p1.x,p2.x,id) (p0.y,...) (p0.z,...)
+    p0 = mk3(X.x, Y.x, Z.x); p1 = mk3(X.y, Y.y, Z.y); p2 = mk3(X.z, Y.z, Z.z);
 }
 __device__ __forceinline__ f3 hit_position(const Hit& h, f3 p0, f3 p1, f3 p2) {
     float b1 = h.u, b2 = h.v, b0 = (1.f - b1) - b2;

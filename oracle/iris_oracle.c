@@ -24,8 +24,9 @@
  * Arithmetic contract for the intersection (so that a different implementation can be compared
  * bit for bit): all operations are IEEE-754 binary32, no contraction other than the explicit
  * fmaf() calls written below (compile with -ffp-contract=off):
- *     cross(a,b) = ( fma(a.y,b.z,-(a.z*b.y)), fma(a.z,b.x,-(a.x*b.z)), fma(a.x,b.y,-(a.y*b.x)) )
+ *     cross(a,b) = ( fma(a.y,b.z,-(a.z*b.y)), fma(a.z,b.x,-(a.x*b.z)), fma(a.x,b.y,-(a.y*b.x)) )      (geometric normal)
  *     dot(a,b)   = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+ *     ray-space row:  fma(m.x,p.x, fma(m.y,p.y, fma(m.z,p.z, c)));   edge functions: plain products, plain difference (tri_test)
  * Closest hit = lexicographic minimum of (t, triangle index) over all triangles that pass the test.
  */
 #include <math.h>
@@ -619,20 +620,48 @@ typedef struct {
 
 typedef struct { float t, u, v; int64_t tri; } orc_hit;
 
-/* Moeller-Trumbore, arithmetic contract of the header */
-static inline int tri_test(const orc_scene *sc, int64_t f, v3 o, v3 d, float *t_, float *u_, float *v_) {
+/* Watertight ray / triangle test (Woop, Benthin, Wald 2013, "Watertight Ray/Triangle Intersection", JCGT 2(1), section 3), arithmetic
+ * contract of the header:
+ *   kz = axis of d's largest magnitude (ties: x before y before z), kx = kz + 1, ky = kx + 1 (mod 3; no winding swap: nothing is culled by
+ *   orientation);  sz = 1 / d[kz],  sx = d[kx] * sz,  sy = d[ky] * sz;
+ *   per vertex P:  z = P[kz] - o[kz],  x = fma(-sx, z, P[kx] - o[kx]),  y = fma(-sy, z, P[ky] - o[ky]);
+ *   U = Cx*By - Cy*Bx, V = Ax*Cy - Ay*Cx, W = Bx*Ay - By*Ax with plain products and a plain difference; if any of them is 0 all three are
+ *   re-evaluated in double and rounded to float;  det = (U + V) + W;  t = (fma(U, Az, fma(V, Bz, W*Cz)) * sz) * (1/det);
+ *   (b1, b2) = (V, W) * (1/det);  accept iff no two of U, V, W have strictly opposite signs and 0 <= t < inf.
+ * Every vertex is mapped by the same function of (vertex, ray) in every triangle it belongs to; rnd(a*b) - rnd(c*d) is exactly antisymmetric
+ * in the two vertices and never has the opposite sign of the exact value, and a zero gets its exact sign from the double evaluation: shared
+ * edges and shared vertices cannot leak. */
+typedef struct { float ox, oy, oz, sx, sy, sz; int kx, ky, kz; } ray_xf;
+static inline float pick3(v3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+static inline ray_xf ray_xform(v3 o, v3 d) {
+    ray_xf x;
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    x.kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    x.kx = x.kz == 2 ? 0 : x.kz + 1; x.ky = x.kx == 2 ? 0 : x.kx + 1;
+    x.sz = 1.0f / pick3(d, x.kz);
+    x.sx = pick3(d, x.kx) * x.sz; x.sy = pick3(d, x.ky) * x.sz;
+    x.ox = pick3(o, x.kx); x.oy = pick3(o, x.ky); x.oz = pick3(o, x.kz);
+    return x;
+}
+static inline int tri_test(const orc_scene *sc, int64_t f, const ray_xf *x, float *t_, float *u_, float *v_) {
     const int32_t *fi = sc->faces + f * 3;
     v3 p0 = v3_ld(sc->verts + (int64_t)fi[0] * 3), p1 = v3_ld(sc->verts + (int64_t)fi[1] * 3), p2 = v3_ld(sc->verts + (int64_t)fi[2] * 3);
-    v3 e1 = v3_sub(p1, p0), e2 = v3_sub(p2, p0);
-    v3 pvec = x_cross(d, e2);
-    float det = x_dot(e1, pvec);
+    float Atz = pick3(p0, x->kz) - x->oz, Btz = pick3(p1, x->kz) - x->oz, Ctz = pick3(p2, x->kz) - x->oz;
+    float Ax = fmaf(-x->sx, Atz, pick3(p0, x->kx) - x->ox), Ay = fmaf(-x->sy, Atz, pick3(p0, x->ky) - x->oy);
+    float Bx = fmaf(-x->sx, Btz, pick3(p1, x->kx) - x->ox), By = fmaf(-x->sy, Btz, pick3(p1, x->ky) - x->oy);
+    float Cx = fmaf(-x->sx, Ctz, pick3(p2, x->kx) - x->ox), Cy = fmaf(-x->sy, Ctz, pick3(p2, x->ky) - x->oy);
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (fminf(fminf(fabsf(U), fabsf(V)), fabsf(W)) == 0.f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    float det = (U + V) + W;
     float inv_det = 1.0f / det;
-    v3 tvec = v3_sub(o, p0);
-    float u = x_dot(tvec, pvec) * inv_det;
-    v3 qvec = x_cross(tvec, e1);
-    float v = x_dot(d, qvec) * inv_det;
-    float t = x_dot(e2, qvec) * inv_det;
-    if (u >= 0.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < INFINITY) { *t_ = t; *u_ = u; *v_ = v; return 1; }
+    float t = (fmaf(U, Atz, fmaf(V, Btz, W * Ctz)) * x->sz) * inv_det;
+    float u = V * inv_det, v = W * inv_det;      /* (b1, b2): p = b0 p0 + b1 p1 + b2 p2 */
+    float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
+    if (!(mn < 0.f && mx > 0.f) && t >= 0.f && t < INFINITY) { *t_ = t; *u_ = u; *v_ = v; return 1; }   /* det == 0: t is NaN or +-inf */
     return 0;
 }
 static inline void hit_update(orc_hit *h, float t, float u, float v, int64_t f) {
@@ -641,9 +670,10 @@ static inline void hit_update(orc_hit *h, float t, float u, float v, int64_t f) 
 
 static orc_hit intersect_brute(const orc_scene *sc, v3 o, v3 d) {
     orc_hit h = {INFINITY, 0.f, 0.f, -1};
+    const ray_xf xf = ray_xform(o, d);
     for (int64_t f = 0; f < sc->nf; ++f) {
         float t, u, v;
-        if (tri_test(sc, f, o, d, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
+        if (tri_test(sc, f, &xf, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
     }
     return h;
 }
@@ -769,6 +799,7 @@ static orc_hit intersect_bvh(const orc_scene *sc, v3 o, v3 d, int64_t *n_nodes, 
     orc_hit h = {INFINITY, 0.f, 0.f, -1};
     if (sc->nf == 0) return h;
     v3 id = v3_make(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const ray_xf xf = ray_xform(o, d);
     int32_t stack[128]; int sp = 0;
     int32_t cur = 0; float tn;
     if (n_nodes) ++*n_nodes;
@@ -779,7 +810,7 @@ static orc_hit intersect_bvh(const orc_scene *sc, v3 o, v3 d, int64_t *n_nodes, 
             for (int32_t i = n->start; i < n->start + n->count; ++i) {
                 float t, u, v; int64_t f = sc->order[i];
                 if (n_tris) ++*n_tris;
-                if (tri_test(sc, f, o, d, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
+                if (tri_test(sc, f, &xf, &t, &u, &v)) { if (h.tri < 0) { h.t = t; h.u = u; h.v = v; h.tri = f; } else hit_update(&h, t, u, v, f); }
             }
         } else {
             float tl, tr;

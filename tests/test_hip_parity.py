@@ -290,7 +290,7 @@ def test_bake_box_golden(dev, tmp_path):
     assert rel_l2(N(Ld), g["Ld"]) <= 1e-4          # the north-star bar, against the reference replay
     for r_idx, r in enumerate(g["roughness_level"]):
         Ls0, Ls1, tri = bs.bake_specular(sc, em, pos, nrm, wo, float(r), spp, u2=T(g[f"u2_spec_{r_idx}"], dev), want_tri=True)
-        assert (N(tri) == g[f"tri_next_spec_{r_idx}"]).mean() >= 0.9995, r_idx
+        assert (N(tri) == g[f"tri_next_spec_{r_idx}"]).mean() >= 0.999, r_idx      # (the box walls are axis-aligned: a grazing sample whose origin position + eps * wi rounds INTO the wall plane meets that wall at t = +-1e-9, a coin toss on the last bit of wi; its weight is ~0)
         assert rel_l2(N(Ls0), g[f"Ls0_{r_idx}"]) <= 1e-4, r_idx
         assert rel_l2(N(Ls1), g[f"Ls1_{r_idx}"]) <= 1e-4, r_idx
 
@@ -594,7 +594,7 @@ def test_full_size_1080p_determinism_and_kernel_agreement(dev, room_setup):
     xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
     g = bs.primary_hits(s["sc"], xs, ds, image_width=W)
     P = g["position"].shape[0]
-    assert 0.9999 * H * W <= P <= H * W      # (a handful of rays slip through Moeller-Trumbore edge cracks of the displaced walls)
+    assert P == H * W                        # closed room, watertight triangle test: every primary ray hits
     args = (s["sc"], s["em"], g["position"], g["normal"], g["wo"], [None, 1.0], [spp, spp])
     r1 = bs.bake_lobes(*args, seed=13, stream_ids=[0, 6], pix_id=g["pix_id"])
     r2 = bs.bake_lobes(*args, seed=13, stream_ids=[0, 6], pix_id=g["pix_id"])
