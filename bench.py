@@ -27,6 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_FILE = "pmc_r3.json"
 N_SIMD, N_CU = 1024, 256
 
 
@@ -90,15 +91,15 @@ def spawn_workers(n):
 
 
 def load_pmc(rays_per_launch, node_bytes):
-    """Per-launch counters of the timed kernel from the committed rocprofv3 passes (profiles/pmc_r2.json; PMC counters cannot be read from
+    """Per-launch counters of the timed kernel from the committed rocprofv3 passes (profiles/pmc_r3.json; PMC counters cannot be read from
     inside this process).  Refused -- reported as stale -- unless they were taken on exactly the kernel sources this library was built
     from and on the same launch size."""
     from iris_amd import _lib as L
-    path = os.path.join(REPO, "profiles", "pmc_r2.json")
+    path = os.path.join(REPO, "profiles", PMC_FILE)
     try:
         pj = json.load(open(path))
     except Exception as e:     # noqa
-        return None, f"profiles/pmc_r2.json unreadable ({e})"
+        return None, f"profiles/{PMC_FILE} unreadable ({e})"
     have = L.source_hash()
     if pj.get("source_hash") != have:
         return None, f"stale: profile taken on kernel sources {pj.get('source_hash')}, this build is {have}"
@@ -357,6 +358,9 @@ def main():
             hbm_ach = traffic / pr * rate / 1e9
             roofs = {
                 "valu": {"achieved": round(valu_ach, 1), "peak": round(valu_peak, 1), "unit": "G VALU issue quad-cycles/s", "frac": round(valu_ach / valu_peak, 4),
+                         "frac_in_the_profiled_run": round(quads_per_ray * pr / (pj["duration"]["avg_ns"] * 1e-9) / 1e9 / valu_peak, 4),
+                         "frac_note": "frac = the profiled issue quad-cycles per ray x THIS run's ray rate; frac_in_the_profiled_run = the same counters over the profiled launch's own duration; "
+                                      "pure instruction streams top out at 0.88 (v_fma_f32, dual issue) ... 0.94-0.97 (4- and 8-cycle classes): profiles/r3_counter_calibration.json",
                          "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "issue_quads_per_ray": round(quads_per_ray, 1),
                          "dual_issued_share_of_instructions": round(2 * c["SQ_ACTIVE_INST_VALU2"] / c["SQ_INSTS_VALU"], 3), "profiled_clock_GHz": round(clock / 1e9, 3),
                          "simd_lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"] * 64, 1), 3)},
@@ -365,12 +369,13 @@ def main():
                           "l1_hit": round(1 - l1_miss, 3), "l2_hit": round(1 - l2_miss, 3), "ta_busy_counter": round(c["TA_TA_BUSY_sum"] / N_CU / (c["GRBM_GUI_ACTIVE"] / 8), 3),
                           "td_busy_counter": round(c["TD_TD_BUSY_sum"] / N_CU / (c["GRBM_GUI_ACTIVE"] / 8), 3)},
                 "hbm": {"achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
-                        "bytes_per_ray": round(traffic / pr, 1), "note": "raw FETCH_SIZE + WRITE_SIZE (random 64-B line fetches; the guide's x2 correction is calibrated on wide streams and is not applied)"},
+                        "bytes_per_ray": round(traffic / pr, 1), "note": "raw FETCH_SIZE + WRITE_SIZE: calibrated on known traffic (profiles/r3_counter_calibration.json) FETCH_SIZE reads 1.05 x the bytes of random 64-B record fetches "
+                                "(this kernel's pattern) and 0.50 x those of a wide coalesced stream (the guide's case); were every fetch of the stream kind the fraction would be twice this"},
             }
             bound = max(roofs, key=lambda k: roofs[k]["frac"])
         rl = {"kernel": "bake_view_kernel<Q8> (all lobes of a view, one persistent launch)", "launch_ms": round(avg_ms, 3), "launches": len(ms),
               "rays_per_launch": int(rays_per_launch), "mrays_per_s_kernel": round(rate / 1e6, 1), "pmc_source": src,
-              "pmc_file": "profiles/pmc_r2.json" if pj else None, "roofs": roofs, "traffic": traffic,
+              "pmc_file": "profiles/" + PMC_FILE if pj else None, "roofs": roofs, "traffic": traffic,
               "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "algorithmic_GBps": round(bytes_per_ray * rate / 1e9, 1),
               "algorithmic_note": "SURVEY 8(d) byte model; these bytes are served by L1 / L2 / Infinity Cache, so the figure exceeds the HBM peak and is not a roof",
               "work_per_ray": work}
@@ -405,8 +410,18 @@ def main():
         # thread count: the host may expose more hardware threads than this job can use (cgroup quota / SMT): every candidate of
         # {all, 1/2, 1/4, 1/8} is calibrated on a short sample and reported; the headline sample runs with the fastest
         ncpu = os.cpu_count() or 1
+        try:
+            n_aff = len(os.sched_getaffinity(0))
+        except Exception:     # noqa
+            n_aff = ncpu
+        cpu_max = None
+        for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                cpu_max = open(f).read().strip(); break
+            except Exception:     # noqa
+                pass
         calib = {}
-        for th in sorted({max(1, ncpu // d) for d in (1, 2, 4, 8)}):
+        for th in sorted({max(1, n_aff // d) for d in (1, 2, 4, 8, 16, 32)} | {min(n_aff, 8)}):
             oracle.set_num_threads(th)
             cpu_run(max(th * 8, 64))
             n, dtc = cpu_run(max(th * 48, 512))
@@ -421,6 +436,7 @@ def main():
         except Exception:     # noqa
             pass
         result["cpu_baseline"] = {"value": round(n / dtc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "cpu_model": cpu_model, "hw_threads": ncpu,
+                                  "sched_getaffinity": n_aff, "cgroup_cpu_max": cpu_max, "mrays_per_s_per_thread": round(n / dtc / 1e6 / threads, 4),
                                   "calibration_mrays_per_s_by_threads": calib,
                                   "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, OpenMP x{threads}"}
         result["gpu_over_cpu"] = round(value / (n / dtc / 1e6), 1)

@@ -50,10 +50,11 @@ typedef struct {
     int32_t layout;        /* IRIS_BVH4_F32 | IRIS_BVH4_Q8 */
     int32_t n_nodes;       /* wide nodes */
     int32_t node_bytes;    /* bytes per node as stored in HBM */
-    int32_t tri_bytes;     /* stride of a leaf-triangle record (64: p0, e1, e2, id, p1, p2)  */
+    int32_t tri_bytes;     /* stride of a leaf-triangle record (64: component-major (p0.x,p1.x,p2.x,id) (y...) (z...), csrc/iris_trace.h) */
     int32_t depth;         /* wide-tree depth */
     int32_t n_leaf_records;/* leaf-triangle records: n_triangles + the extra references of split long triangles */
-    float   sah_cost;      /* SAH cost of the binary tree the wide tree was collapsed from */
+    float   sah_cost;      /* cost of the WIDE tree as the collapse minimises it: sum over wide nodes of A_node + sum over leaves of A_leaf * records *
+                              tri_cost (0.7), areas relative to the root, duplicated references of split triangles included (csrc/bvh_build.cpp) */
     float   build_seconds;
 } iris_scene_info;
 

@@ -135,6 +135,15 @@ def require_gpu(t, dtype, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def no_autograd(fn, *tensors):
+    """The entry points behind `fn` are raw HIP kernels writing into fresh buffers: they have no backward pass.  The reference's counterparts
+    are differentiable torch ops, so handing them a tensor that requires grad (with grad mode on) would silently train with zero / None
+    gradients -- raise instead.  Call under torch.no_grad() or pass .detach()ed tensors to state that no gradient is wanted."""
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        raise IrisError(f"{fn}: an input requires grad, but this is a HIP kernel without a backward pass (the reference's torch op is differentiable); "
+                        "wrap the call in torch.no_grad() or detach() the inputs")
+
+
 def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 #define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s
 #endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
-#define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: a kernel without scratch fits 6 waves/SIMD (measured +6.5 %)
+#define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: without a scratch-resident stack array the kernel fits 6 (7) waves/SIMD (measured +6.5 %)
 #endif
 
 // One tile (<= kTileRays rays = tile_px consecutive valid pixels x spp) of one lobe, by one 256-thread workgroup.
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlock, IRIS_TILE_WAVES) void bake_view_kernel(View
     static_assert(kTileStack * kBlock * 4 >= kTileRays + 2 * 256 * 4, "stack region too small to alias the sort keys");
     const int tid = threadIdx.x;
     float4* res = v.base.scratch + (size_t)blockIdx.x * kTileRays * 2;
-    uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform; no private scratch in this kernel
+    uint32_t* ovf = v.base.stack_ovf + (size_t)blockIdx.x * (kStackCapacity - kTileStack) * kBlock;   // wave-uniform: the traversal stacks never go to private scratch (register spills outside the node / leaf loops do: make resource-usage)
     for (;;) {
         __syncthreads();
         if (tid == 0) { s_tile = (int)claim_tile(v.base.tile_counter, v.n_tiles); s_chunk = 0; }

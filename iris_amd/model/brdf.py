@@ -34,8 +34,10 @@ class BaseBRDF(nn.Module):
 
     def eval_specular(self, wi, wo, normal, roughness):
         """(brdf_spec0 Bx1, brdf_spec1 Bx1, pdf Bx1): the GGX lobe split by the two Schlick terms, F = ks F0 + F1 (model/brdf.py:90-110);
-        D, G and the Fresnel terms are the HIP helpers of iris_amd.utils.ops"""
+        D, G and the Fresnel terms are the HIP helpers of iris_amd.utils.ops.  No backward pass (the reference's version carries gradient to
+        roughness, wi and normal): inputs that require grad raise instead of being cut off silently."""
         from ..utils import ops
+        L.no_autograd("BaseBRDF.eval_specular", wi, wo, normal, roughness)
         wi = L.require_gpu(wi, torch.float32, "wi").reshape(-1, 3)
         wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
         normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
@@ -52,7 +54,8 @@ class BaseBRDF(nn.Module):
         return DG * f0 / 4.0 * n_l, DG * f1 / 4.0 * n_l, pdf
 
     def sample_diffuse(self, sample2, normal):
-        """Cosine-weighted direction, pdf = relu(n.wi)/pi, weight = 1 (model/brdf.py:78-88)."""
+        """Cosine-weighted direction, pdf = relu(n.wi)/pi, weight = 1 (model/brdf.py:78-88).  No backward pass."""
+        L.no_autograd("BaseBRDF.sample_diffuse", sample2, normal)
         sample2 = L.require_gpu(sample2, torch.float32, "sample2").reshape(-1, 2)
         normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
         B = sample2.shape[0]
@@ -65,7 +68,9 @@ class BaseBRDF(nn.Module):
 
     def sample_specular(self, sample2, wo, normal, roughness):
         """GGX half-vector sampling and the two Fresnel-split weights (model/brdf.py:112-136).
-        roughness: python float or 0-d tensor (bake_shading.py:161 iterates a linspace), or one value per sample (Bx1)."""
+        roughness: python float or 0-d tensor (bake_shading.py:161 iterates a linspace), or one value per sample (Bx1).
+        No backward pass (the reference's weights carry gradient to roughness; its sampled direction does not: model/brdf.py:46 uses .data)."""
+        L.no_autograd("BaseBRDF.sample_specular", sample2, wo, normal, roughness)
         sample2 = L.require_gpu(sample2, torch.float32, "sample2").reshape(-1, 2)
         wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
         normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
@@ -98,7 +103,9 @@ class BaseBRDF(nn.Module):
 
     def eval_brdf(self, wi, wo, normal, mat):
         """BRDF value (already multiplied by NoL) and the 50/50 diffuse + GGX sampling pdf (model/brdf.py:138-175).
-        mat: {'albedo' Bx3, 'roughness' Bx1, 'metallic' Bx1}.  Returns brdf Bx3, pdf Bx1."""
+        mat: {'albedo' Bx3, 'roughness' Bx1, 'metallic' Bx1}.  Returns brdf Bx3, pdf Bx1.  No backward pass: a material that requires
+        grad raises (path_tracing_single differentiates w.r.t. the emitter radiance only, as train_emitter.py does)."""
+        L.no_autograd("BaseBRDF.eval_brdf", wi, wo, normal, *[mat[k] for k in ("albedo", "roughness", "metallic")])
         wi = L.require_gpu(wi, torch.float32, "wi").reshape(-1, 3)
         wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
         normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
@@ -112,7 +119,8 @@ class BaseBRDF(nn.Module):
 
     def sample_brdf(self, sample1, sample2, wo, normal, mat):
         """importance sampling: diffuse lobe where sample1 > 0.5, GGX otherwise; returns wi Bx3, pdf Bx1, brdf/pdf Bx3
-        (model/brdf.py:177-210)."""
+        (model/brdf.py:177-210).  No backward pass."""
+        L.no_autograd("BaseBRDF.sample_brdf", wo, normal, *[mat[k] for k in ("albedo", "roughness", "metallic")])
         sample1 = L.require_gpu(sample1, torch.float32, "sample1").reshape(-1)
         sample2 = L.require_gpu(sample2, torch.float32, "sample2").reshape(-1, 2)
         wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)

@@ -37,7 +37,14 @@ class VoxelSLF(nn.Module):
 
     @staticmethod
     def _tver(t):
-        return (t._version, t.data_ptr(), str(t.device), tuple(t.shape))
+        # identity + version of the uploaded tensor.  The tensor object itself is kept (not its data_ptr): a rebound buffer
+        # (`vslf.radiance = vslf.radiance / n`) is a new object even when the caching allocator hands it the address -- and _version 0 -- of
+        # the tensor that was uploaded before, and holding the reference keeps that address from being reused while the key is alive.
+        return (t, t._version)
+
+    @staticmethod
+    def _same(a, b):
+        return a is not None and b is not None and a[0] is b[0] and a[1] == b[1]
 
     def handle(self, device, need_radiance=True):
         """Device-side tables (int32 index grid + padded radiance rows).  They follow the module: the tables are rebuilt when `inds`
@@ -45,7 +52,7 @@ class VoxelSLF(nn.Module):
         re-uploaded when only `radiance` did (scatter_add, mean pooling) -- lazily, the next time a lookup needs them."""
         device = torch.device(device)
         iv = self._tver(self.inds)
-        if self._h is None or self._h_device != device or self._ver != iv:
+        if self._h is None or self._h_device != device or not self._same(self._ver, iv):
             self.refresh()
             inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
             rad = L.host_f32(self.radiance).reshape(-1, 3)
@@ -53,7 +60,7 @@ class VoxelSLF(nn.Module):
             L.check(L.lib().iris_slf_create(inds.ctypes.data_as(C.c_void_p), self.H, rad.ctypes.data_as(C.c_void_p), rad.shape[0],
                                             self.voxel_min, self.voxel_max, device.index or 0, C.byref(h)))
             self._h, self._h_device, self._ver, self._rver = h, device, iv, self._tver(self.radiance)
-        elif need_radiance and self._rver != self._tver(self.radiance):
+        elif need_radiance and not self._same(self._rver, self._tver(self.radiance)):
             rr = self.radiance.detach().to(device=device, dtype=torch.float32).contiguous()
             with torch.cuda.device(device):
                 L.check(L.lib().iris_slf_set_radiance(self._h, L.ptr(rr), rr.shape[0], L.stream()))

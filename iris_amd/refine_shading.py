@@ -117,7 +117,8 @@ def main(argv=None):
     parser.add_argument("--indir_depth", type=int, default=INDIR_DEPTH)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--compression", type=str, default="zip", choices=["none", "zips", "zip"])
-    parser.add_argument("--overwrite", action="store_true")
+    parser.add_argument("--overwrite", action="store_true", help="(accepted for symmetry with bake_shading; refining always overwrites, as the reference does)")
+    parser.add_argument("--resume", action="store_true", help="skip the views a previous refine run with the same settings has completed (marked by a .refined sidecar)")
     parser.add_argument("--denoise", type=str, default="atrous", choices=["atrous", "none"])
     args = parser.parse_args(argv)
 
@@ -158,15 +159,32 @@ def main(argv=None):
         denoiser = Denoiser(img_hw[::-1], device)
     writer = MapWriter(device, img_hw, args.compression)
     start_time = time.time()
+    # The reference runs bake_shading and refine_shading on the SAME --output: the refined maps replace the bake's 13 files of every view in place
+    # (refine_shading.py:126,172-173).  So a view's files existing says nothing about whether it has been refined: every view is rendered and
+    # overwritten, unless --resume finds the sidecar a completed refine of that view left behind (keyed on what determines the result).
+    import hashlib
+    ck = ""
+    if args.ckpt and os.path.exists(args.ckpt):
+        st = os.stat(args.ckpt); ck = "{}:{}:{}".format(os.path.abspath(args.ckpt), st.st_size, int(st.st_mtime))
+    run_key = hashlib.sha256(repr((args.material, ck, args.spp_diffuse, args.spp_specular, args.indir_depth, args.seed, args.res_scale, args.denoise,
+                                   tuple(img_hw))).encode()).hexdigest()[:16]
+    done = []
     for im_id in range(rank, len(views), world):
         files = output_files(args.output, im_id)
-        if not args.overwrite and all(os.path.exists(f) for f in files):
+        marker = os.path.join(args.output, "diffuse", "{:03d}.refined".format(im_id))
+        if args.resume and os.path.exists(marker) and open(marker).read().strip() == run_key and all(os.path.exists(f) for f in files):
             continue
+        if os.path.exists(marker):
+            os.remove(marker)
         torch.manual_seed(args.seed * 1000003 + im_id); torch.cuda.manual_seed(args.seed * 1000003 + im_id)     # the integrators draw with torch.rand
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
         out = refine_view(scene, emitter, material_net, xs, ds, args.spp_diffuse, args.spp_specular, args.indir_depth, denoiser=denoiser)
         writer.submit(files, torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3))
-    writer.close()
+        done.append(marker)
+    writer.close()                                             # every file is on disk from here on
+    for marker in done:
+        with open(marker, "w") as fh:
+            fh.write(run_key + "\n")
     torch.cuda.synchronize()
     print("[refine_shading] rank {}: {:.2f} s".format(rank, time.time() - start_time))
 

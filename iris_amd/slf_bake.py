@@ -20,27 +20,41 @@ from .utils.gbuffer import scatter_add_rows, voxel_histogram
 from .utils.path_tracing import ray_intersect
 
 
-def _hits(scene, batch, device):
-    """Primary hits of one view.  The reference re-traces every view in each of its passes (bounds, histogram, pooling); here the
-    result is kept with the batch (a few tens of MB per 1080p view against 288 GB), so a view is traced once."""
-    hit = batch.get("_iris_hits") if isinstance(batch, dict) else None
-    if hit is None or hit[0].device != torch.device(device) or hit[3] is not scene:
+def _same_device(a, b):
+    a, b = torch.device(a), torch.device(b)       # 'cuda' and 'cuda:0' are the same place: compare type and resolved index
+    idx = lambda d: d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else 0)
+    return a.type == b.type and idx(a) == idx(b)
+
+
+def _hits(scene, batch, device, cache=False):
+    """Primary hits of one view: (positions, triangle index int32, valid).  The reference re-traces every view in each of its passes (bounds,
+    histogram, pooling).  With cache=True the result is kept with the batch dict (28 B per pixel, i.e. 58 MB per 1080p view -- opt-in, because
+    it pins that memory and the scene for as long as the caller keeps its batches; drop_hits() releases it) so a view is traced once."""
+    hit = batch.get("_iris_hits") if (cache and isinstance(batch, dict)) else None
+    if hit is None or not _same_device(hit[0].device, device) or hit[3] is not scene:
         rays = batch["rays"].to(device)
         positions, _, _, idx, valid = ray_intersect(scene, rays[..., :3].contiguous(), rays[..., 3:6].contiguous())
-        hit = (positions, idx, valid, scene)
-        if isinstance(batch, dict):
+        hit = (positions, idx.to(torch.int32), valid, scene)
+        if cache and isinstance(batch, dict):
             batch["_iris_hits"] = hit
-    return hit[0], hit[1], hit[2]
+    return hit[0], hit[1].long(), hit[2]
 
 
-def scene_bounds(scene, views, dataset, device):
+def drop_hits(views):
+    """Release the primary hits _hits(cache=True) attached to the batches."""
+    for batch in views:
+        if isinstance(batch, dict):
+            batch.pop("_iris_hits", None)
+
+
+def scene_bounds(scene, views, dataset, device, cache=False):
     """slf_bake.py:69-93 including its scannetpp centre (``voxel_c = voxel_min + voxel_max``, not halved: kept, the files depend on it)."""
     # running min / max stay on the device (one host sync at the end instead of three per view); misses are masked out with the
     # identities of the reference's start values (1000, 0)
     lo = torch.tensor(1000.0, device=device)
     hi = torch.tensor(0.0, device=device)
     for batch in views:
-        positions, _, valid = _hits(scene, batch, device)
+        positions, _, valid = _hits(scene, batch, device, cache)
         v = valid[:, None]
         lo = torch.minimum(lo, torch.where(v, positions, lo).min())
         hi = torch.maximum(hi, torch.where(v, positions, hi).max())
@@ -54,22 +68,23 @@ def scene_bounds(scene, views, dataset, device):
     return torch.as_tensor(voxel_min, dtype=torch.float32), torch.as_tensor(voxel_max, dtype=torch.float32)
 
 
-def visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device):
+def visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device, cache=False):
     """slf_bake.py:95-114: SpatialHist (res,res,res) f32 [z,y,x]; mask = SpatialHist > 0."""
     hist = torch.zeros(res_spatial, res_spatial, res_spatial, device=device, dtype=torch.float32)
     for batch in views:
-        positions, _, valid = _hits(scene, batch, device)
+        positions, _, valid = _hits(scene, batch, device, cache)
         voxel_histogram(positions[valid], float(voxel_min), float(voxel_max), res_spatial, hist)      # (an empty selection is a no-op)
     return hist
 
 
-def pool_radiance(scene, views, vslf, device):
+def pool_radiance(scene, views, vslf, device, cache=False):
     """slf_bake.py:120-138 / slf_refine.py:90-106: scatter every valid primary hit's radiance into its voxel, then average."""
     vslf = vslf.to(device)
     for batch in views:
-        positions, _, valid = _hits(scene, batch, device)
+        positions, _, valid = _hits(scene, batch, device, cache)
         vslf.scatter_add(positions[valid], batch["rgbs"].to(device=device, dtype=torch.float32)[valid])
-    vslf.radiance = vslf.radiance / vslf.count[..., None].float().clamp_min(1)      # (the handle re-uploads the rows at the next lookup)
+    vslf.radiance = vslf.radiance / vslf.count[..., None].float().clamp_min(1)
+    vslf.refresh()                                    # the buffer was rebound: the device tables are rebuilt at the next lookup
     return vslf
 
 
@@ -77,11 +92,14 @@ def bake_slf(scene, views, res_spatial=256, dataset="scannetpp", device="cuda"):
     """-> the dict slf_bake.py:140-145 saves as vslf.npz: {'mask', 'voxel_min', 'voxel_max', 'weight'}  (tensors on the host)."""
     views = list(views)
     device = torch.device(device)
-    voxel_min, voxel_max = scene_bounds(scene, views, dataset, device)
-    hist = visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device)
-    mask = hist > 0
-    vslf = VoxelSLF(mask.cpu(), voxel_min.item(), voxel_max.item())
-    vslf = pool_radiance(scene, views, vslf, device)
+    try:                                              # the three passes share one primary trace per view; nothing stays attached to the batches
+        voxel_min, voxel_max = scene_bounds(scene, views, dataset, device, cache=True)
+        hist = visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device, cache=True)
+        mask = hist > 0
+        vslf = VoxelSLF(mask.cpu(), voxel_min.item(), voxel_max.item())
+        vslf = pool_radiance(scene, views, vslf, device, cache=True)
+    finally:
+        drop_hits(views)
     return {"mask": mask.cpu(), "voxel_min": voxel_min.item(), "voxel_max": voxel_max.item(),
             "weight": {k: v.cpu() for k, v in vslf.state_dict().items()}}
 

@@ -1,4 +1,8 @@
-"""Shading helpers of the hot path that are callable on their own (reference: utils/ops.py)."""
+"""Shading helpers of the hot path that are callable on their own (reference: utils/ops.py).
+
+Unlike the reference's torch expressions these are HIP kernels WITHOUT a backward pass: an input that requires grad (with grad mode on) raises
+IrisError instead of silently cutting the graph.  The differentiable pieces of this package are the autograd.Functions of
+utils/path_tracing.py (path_tracing_single w.r.t. the emitter radiance) and utils/shading_cache.py (the BRDF trainer's shading combine)."""
 import torch
 
 from .. import _lib as L
@@ -7,6 +11,7 @@ from .. import _lib as L
 def lerp_specular(specular, roughness):
     """Interpolate the 6 baked specular levels by roughness (utils/ops.py:99-118).
     specular: Bx6x3, roughness: Bx1 in [0.02,1.0] -> Bx3."""
+    L.no_autograd("lerp_specular", specular, roughness)      # (the differentiable combine is utils/shading_cache.shade_cached)
     specular = L.require_gpu(specular, torch.float32, "specular")
     roughness = L.require_gpu(roughness, torch.float32, "roughness").reshape(-1)
     B, R, _ = specular.shape
@@ -30,6 +35,7 @@ def _flat(*xs):
 
 def _ggx(op, a, b=None, c=None, two=False):
     args = [x for x in (a, b, c) if x is not None]
+    L.no_autograd("utils.ops GGX / Fresnel helper", *args)
     flat, shape = _flat(*args)
     flat += [None] * (3 - len(flat))
     n = flat[0].numel()
@@ -43,6 +49,7 @@ def _ggx(op, a, b=None, c=None, two=False):
 
 def get_normal_space(normal):
     """normal (...,3) unit -> (...,3,3) with columns tangent, bitangent, normal (utils/ops.py:12-30)"""
+    L.no_autograd("get_normal_space", normal)
     n = L.require_gpu(normal, torch.float32, "normal")
     flat = n.reshape(-1, 3).contiguous()
     out = torch.empty(flat.shape[0], 3, 3, device=n.device, dtype=torch.float32)
@@ -53,6 +60,7 @@ def get_normal_space(normal):
 
 def angle2xyz(theta, phi):
     """spherical -> unit vector (...,3) (utils/ops.py:32-44)"""
+    L.no_autograd("angle2xyz", theta, phi)
     (t, p), shape = _flat(theta, phi)
     out = torch.empty(t.numel(), 3, device=t.device, dtype=torch.float32)
     with torch.cuda.device(t.device):
@@ -62,6 +70,7 @@ def angle2xyz(theta, phi):
 
 def double_sided(V, N):
     """flip N (...,3) towards the viewing direction V, IN PLACE as the reference does, and return it (utils/ops.py:85-96)"""
+    L.no_autograd("double_sided", V, N)
     V = L.require_gpu(V, torch.float32, "V")
     L.require_gpu(N, torch.float32, "N")
     v = V.expand_as(N).reshape(-1, 3).contiguous()

@@ -90,3 +90,20 @@ def test_eval_diffuse_specular_compose_to_eval_brdf():
         for a, c in zip(got, ref):
             np.testing.assert_array_equal(a[rows].cpu().numpy(), c[rows].cpu().numpy())
     np.testing.assert_array_equal(specular_sampler(u2, r, wo, n).cpu().numpy(), got[0].cpu().numpy())
+
+
+def test_raw_kernels_refuse_inputs_that_require_grad(dev):
+    """the reference's utils/ops.py helpers are differentiable torch ops; these are kernels without a backward pass and must say so instead
+    of silently cutting the graph"""
+    from iris_amd import _lib as L
+    from iris_amd.model.brdf import BaseBRDF
+    x = torch.rand(16, device=dev, requires_grad=True)
+    n = torch.nn.functional.normalize(torch.randn(16, 3, device=dev), dim=-1)
+    for call in (lambda: ops.D_GGX(x, 0.3), lambda: ops.G_Smith(x.detach(), x, 0.3), lambda: ops.fresnelSchlick_sep(x), lambda: ops.angle2xyz(x, x.detach()),
+                 lambda: ops.get_normal_space(n.clone().requires_grad_()), lambda: ops.lerp_specular(torch.rand(16, 6, 3, device=dev), x.reshape(-1, 1)),
+                 lambda: BaseBRDF().eval_specular(n, n, n, x.reshape(-1, 1))):
+        with pytest.raises(L.IrisError, match="backward"):
+            call()
+    with torch.no_grad():                                         # stating that no gradient is wanted: fine
+        assert ops.D_GGX(x, 0.3).shape == (16,)
+    assert ops.D_GGX(x.detach(), 0.3).shape == (16,)

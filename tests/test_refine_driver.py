@@ -73,14 +73,29 @@ def test_refine_cli_writes_the_bake_file_set(tmp_path):
     out = str(tmp_path / "out")
     argv = ["--scene", str(scene_dir), "--slf_path", sp, "--emitter_path", ep, "--output", out, "--dataset", "generic", "--cameras", str(tmp_path / "cams.json"),
             "--material", "stub_material:material", "--spp_diffuse", "8", "--spp_specular", "4", "--indir_depth", "2", "--seed", "2"]
+    # the reference's pipeline runs the bake and the refinement on the SAME --output (README; refine_shading.py:126,172-173 overwrite the bake's
+    # files in place): the directory is populated by the bake CLI first, and the refine CLI must replace every file
+    bs.main(["--scene", str(scene_dir), "--slf_path", sp, "--emitter_path", ep, "--output", out, "--dataset", "generic", "--cameras", str(tmp_path / "cams.json"),
+             "--spp_diffuse", "8", "--spps_specular", "4", "4", "4", "4", "4", "4", "--seed", "2"])
+    baked = {f: exr.read_exr(f) for im_id in (0, 1) for f in bs.output_files(out, im_id)}
+    assert len(baked) == 26
     rs.main(argv)
     for im_id in (0, 1):
         files = bs.output_files(out, im_id)
         assert len(files) == 13 and all(os.path.exists(f) for f in files)
         img = exr.read_exr(files[0])
         assert img.shape == (H, W, 3) and np.isfinite(img).all() and float(img.sum()) > 0
+        for f in (files[0], files[5], files[12]):          # multi-bounce maps, not the single-bounce bake
+            assert not np.array_equal(exr.read_exr(f), baked[f]), f
     a, b = exr.read_exr(bs.output_files(out, 0)[0]), exr.read_exr(bs.output_files(out, 1)[0])
     assert not np.array_equal(a, b)                        # same camera, per-view seeds: independent noise
-    mt = os.path.getmtime(bs.output_files(out, 0)[0])
-    rs.main(argv)                                          # resume: nothing is re-rendered
-    assert os.path.getmtime(bs.output_files(out, 0)[0]) == mt
+    f0 = bs.output_files(out, 0)[0]
+    mt = os.stat(f0).st_mtime_ns
+    rs.main(argv + ["--resume"])                           # same settings, completed views: nothing is re-rendered
+    assert os.stat(f0).st_mtime_ns == mt
+    rs.main(argv + ["--resume", "--spp_diffuse", "4"])     # other settings: the marker does not match, the view is rendered again
+    assert os.stat(f0).st_mtime_ns != mt
+    mt = os.stat(f0).st_mtime_ns
+    rs.main(argv)                                          # default: overwrite, as the reference does
+    assert os.stat(f0).st_mtime_ns != mt
+    np.testing.assert_array_equal(exr.read_exr(f0), a)     # (and reproducibly: per-view seeds)

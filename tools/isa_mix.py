@@ -33,7 +33,7 @@ def main():
         lines = open(out).read().splitlines()
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4iris\d+" + re.escape(args.kernel) + r".*:\s*(;.*)?$", l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    depth, counts, other = 0, {"fast": 0, "complex": 0, "trans": 0}, {"salu": 0, "vmem": 0, "lds": 0}
+    depth, counts, other = 0, {"fast": 0, "complex": 0, "trans": 0}, {"salu": 0, "vmem": 0, "lds": 0, "lane_ops": 0}
     per_op = {}
     for l in lines[start:end]:
         m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?$", l)
@@ -51,7 +51,10 @@ def main():
         op = t.split()[0]
         base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
         if base.startswith("v_"):
-            if base in ("v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32") or base.startswith("v_mfma"):
+            if base in ("v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32"):
+                other["lane_ops"] += 1          # (SGPR spill traffic and wave-uniform broadcasts: VALU issue slots too, reported separately)
+                continue
+            if base.startswith("v_mfma"):
                 continue
             cls = "fast" if base in FAST else "trans" if base in TRANS else "complex"
             counts[cls] += 1
