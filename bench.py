@@ -130,6 +130,12 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the 7 independent lobe launches of a view are spread over (--per-lobe)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: bake only the stripes rank 0 of an N-GPU run would own (no collective), to "
                     "measure the per-rank time of a strong-scaling run on one GPU; the printed value is then NOT the headline metric")
+    ap.add_argument("--shard", choices=["stripes", "views"], default=os.environ.get("IRIS_BENCH_SHARD", "stripes"),
+                    help="N > 1: 'stripes' = every view sharded over the ranks in interleaved row stripes + one gather per view (BASELINE configs[3]; strong scaling); "
+                         "'views' = every rank bakes whole views of the sequence, no collective at all (SURVEY 8(e)'s fallback; weak scaling: N views per step)")
+    ap.add_argument("--gather", choices=["gather", "all_gather"], default=os.environ.get("IRIS_BENCH_GATHER", "gather"),
+                    help="the one collective of a sharded view: gather to rank 0 (north_star; the rank that writes the files) or all_gather")
+    ap.add_argument("--collective-timeout", type=float, default=300.0, help="seconds before a stuck collective aborts the run (a dead rank must not hang the others)")
     ap.add_argument("--long-walls", action="store_true", help="experiments: add the room's six walls once more as 12 large triangles (a decimated scan; see build_workload)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="debug: the rank whose stripes --emulate-world bakes")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="iris_debug_set tuning option (experiments), e.g. bvh_max_leaf=2")
@@ -159,10 +165,12 @@ def main():
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
+        import datetime
+        to = datetime.timedelta(seconds=args.collective_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, timeout=to)   # RCCL over xGMI
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=to)
 
     from iris_amd import _lib as L
     from iris_amd import bake_shading as bs
@@ -177,19 +185,29 @@ def main():
     room, slf_np, emi_np, scene, emitter = build_workload(args, dev)
     info = scene.info()
     K, c2w = synth.camera(H, W, 0)
-    pix_local = sh.local_pixel_ids(H, W, world, rank, device=dev)
+    by_views = world > 1 and args.shard == "views"
+    pix_local = sh.local_pixel_ids(H, W, 1 if by_views else world, 0 if by_views else rank, device=dev)
     if args.emulate_world > 1 and world == 1:
         pix_local = sh.local_pixel_ids(H, W, args.emulate_world, args.emulate_rank % args.emulate_world, device=dev)
     rough = bs.roughness_levels().tolist()
     n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
     one_launch = args.variant == 0 and not args.per_lobe
 
-    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gather_stream = torch.cuda.Stream(device=dev) if (world > 1 and not by_views) else None
+    gatherer = sh.MapGatherer(H, W, world, rank, n_maps, dev, mode=args.gather) if gather_stream is not None else None     # buffers allocated once per run
+    fail_rank, fail_step = int(os.environ.get("IRIS_BENCH_FAIL_RANK", "-1")), int(os.environ.get("IRIS_BENCH_FAIL_STEP", "1"))   # (tests: a rank dying mid-run)
+    n_step = [0]
+    last = [None]
     ev_view = []     # (start, end, rays) HIP events around every bake_view_kernel launch of the timed region, on the launch stream
     ev_gather = []   # the same around the all_gather + permutation (N > 1)
 
     def step(view=0, timed=False):
         """One view: rays -> primary hits (this rank's stripes) -> all lobes (one launch) -> scatter -> one all_gather."""
+        if rank == fail_rank and n_step[0] == fail_step:
+            raise RuntimeError(f"IRIS_BENCH_FAIL_RANK: rank {rank} fails in step {fail_step}")
+        n_step[0] += 1
+        if by_views:
+            view = view * world + rank                                          # every rank its own view of the sequence, no exchange
         c2w = synth.camera(H, W, view % args.views, n_views=args.views)[1]      # the train-view sequence: cameras on a circle (cfg 3)
         xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
         xs, ds = xs[pix_local], ds[pix_local]
@@ -223,7 +241,7 @@ def main():
                 maps[m, g["sel"]] = res; m += 1
             else:
                 maps[m, g["sel"]] = res[0]; maps[m + 1, g["sel"]] = res[1]; m += 2
-        if world > 1:
+        if gatherer is not None:
             # the gather of this view runs on its own stream, beside the next view's kernels (bake_shading's CLI hands the maps to its
             # writer threads the same way); the timed region ends with both streams joined
             done = torch.cuda.Event()
@@ -234,11 +252,12 @@ def main():
                 if timed:
                     g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     g0.record(gather_stream)
-                full = sh.gather_maps(maps, H, W, world, rank)
+                full = gatherer(maps)
                 if timed:
                     g1.record(gather_stream); ev_gather.append((g0, g1))
         else:
             full = maps
+        last[0] = maps
         return rays, full
 
     def sync():
@@ -261,6 +280,7 @@ def main():
         rays_local += r
         marks[i + 1].record()
     sync()
+    last_maps = last[0]
     dt_local = time.perf_counter() - t0
     ms_by_view = [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)]
     t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
@@ -274,26 +294,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
         dist.all_reduce(ranks_seen, op=dist.ReduceOp.SUM)
-        # every rank must hold the same gathered image of the last view (sums in one fixed order: identical bits on identical data)
-        chk = full.double().sum().reshape(1)
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        gather_ok = bool(lo.item() == hi.item()) and bool(torch.isfinite(chk).item()) and float(chk.item()) > 0.0
+        gather_ok = None
+        if gatherer is not None:
+            # the gathered image of the last view holds exactly the ranks' local maps: an order-independent integer checksum (the float bits summed
+            # as int64, wrapping) of what every rank sent, reduced over the ranks, against the same checksum of what a receiving rank holds
+            sent = last_maps.view(torch.int32).to(torch.int64).sum().reshape(1)
+            dist.all_reduce(sent, op=dist.ReduceOp.SUM)
+            got = full.view(torch.int32).to(torch.int64).sum().reshape(1) if full is not None else sent.clone()
+            bad = (got != sent).to(torch.int64)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            finite = torch.tensor([1 if (full is None or bool(torch.isfinite(full).all())) else 0], device=dev)
+            dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+            gather_ok = bool(bad.item() == 0) and bool(finite.item() == 1)
     dt = float(t.item()); rays_total = float(rays_t.item())
     value = rays_total / dt / 1e6
 
     result = {
         "metric": "bake_shading throughput (shading samples/s: secondary rays traced and shaded)", "value": round(value, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if by_views else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"bake_shading train-view sequence ({args.steps} views evenly spaced among {args.views} cameras on a circle, one view per step), {W}x{H}, SPP={spp} per lobe, lobes={lobes} (0=diffuse,1-6=specular), synthetic room "
                                f"seed={args.scene_seed} {info['n_triangles']} triangles, SLF H={args.slf_res}, Philox uniforms",
-                   "pixels_per_view": H * W, "rays_per_step": int(rays_total / max(args.steps, 1)), "ms_by_view": ms_by_view[:32], "sharding": f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 all_gather",
+                   "pixels_per_view": H * W, "rays_per_step": int(rays_total / max(args.steps, 1)), "ms_by_view": ms_by_view[:32], "sharding": (f"{world} ranks x whole views of the sequence ({world} views per step), no collective" if by_views else
+                                                                                                                        f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 {args.gather} per view"),
                    "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"],
                            "sah_cost": round(info["sah_cost"], 3), "build_seconds": round(info["build_seconds"], 2)}},
         "multi_gpu": {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks_seen": int(ranks_seen.item()), "per_rank_ms_per_step": [round(x / max(args.steps, 1) * 1e3, 3) for x in per_rank],
                       "gather_ms": round(float(np.mean([a.elapsed_time(b) for a, b in ev_gather])), 3) if ev_gather else None,
-                      "gather_overlapped": world > 1, "gathered_image_identical_on_all_ranks": gather_ok if world > 1 else None},
+                      "gather_overlapped": gatherer is not None, "collective": (args.gather if gatherer is not None else None),
+                      "gathered_image_matches_what_the_ranks_sent": gather_ok if world > 1 else None},
     }
 
     if rank == 0 and not args.no_roofline and one_launch and ev_view:

@@ -144,6 +144,11 @@ IRIS_API int iris_bake_view(const iris_scene *, const iris_emitter *, const iris
                    const uint32_t *stream_ids, uint64_t seed, float *const *out0, float *const *out1, void *workspace,
                    uint64_t workspace_bytes, iris_stream_t);
 
+/* ---- (e) multi-GPU: one view sharded over the ranks of a node in interleaved row stripes (no reference counterpart: bake_shading.py:41 pins one
+ * device).  After the single collective, `gathered` holds (world, n_maps, n_max, 3): rank r's maps at its local pixels (its rows -- stripe s of
+ * stripe_rows rows belongs to rank s % world -- ascending, row-major, padded to n_max); `full` (n_maps, H*W, 3) receives the image order. */
+IRIS_API int iris_unstripe_maps(const float *gathered, int world, int n_maps, int64_t n_max, int H, int W, int stripe_rows, float *full, iris_stream_t);
+
 /* ---- a10: lerp_specular (utils/ops.py:99-118): specular (B,R,3), roughness (B) -> (B,3) ------------------ */
 IRIS_API int iris_lerp_specular(const float *specular, const float *roughness, int64_t B, int R, float *out, iris_stream_t);
 

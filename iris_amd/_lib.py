@@ -51,6 +51,7 @@ PROTOTYPES = {
     "iris_debug_set": [C.c_char_p, C.c_longlong],
     "iris_bake_view": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _U64, _P, _P, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
+    "iris_unstripe_maps": [_P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P],
     "iris_get_normal_space": [_P, _I64, _P, _P],
     "iris_double_sided": [_P, _P, _I64, _P],
     "iris_angle2xyz": [_P, _P, _I64, _P, _P],

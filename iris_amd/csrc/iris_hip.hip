@@ -553,6 +553,35 @@ extern "C" IRIS_API int iris_lerp_specular(const float* specular, const float* r
     return IRIS_OK;
 }
 
+// ---- multi-GPU: the gathered stripes of a view back into image order (iris_amd/sharding.py; the reference is single-GPU, bake_shading.py:41).
+// gathered[r][m][j] is map m of rank r at its j-th local pixel (the rank's rows -- stripe s of `stripe` rows belongs to rank s % world -- in
+// ascending order, row-major); full[m][row * W + col].  Pure index arithmetic: no index tensors, one pass, reads and writes coalesced along a row.
+__global__ void unstripe_maps_kernel(const float* __restrict__ gathered, int world, int M, int64_t n_max, int H, int W, int stripe, float* __restrict__ full) {
+    const int64_t n_px = (int64_t)H * W, total = n_px * M * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / (n_px * 3), rem = i - m * n_px * 3, p = rem / 3;
+        const int c = (int)(rem - p * 3);
+        const int row = (int)(p / W), col = (int)(p - (int64_t)row * W);
+        const int s = row / stripe, r = s % world;
+        const int64_t j = ((int64_t)(s / world) * stripe + (row - s * stripe)) * W + col;
+        full[i] = gathered[(((int64_t)r * M + m) * n_max + j) * 3 + c];
+    }
+}
+extern "C" IRIS_API int iris_unstripe_maps(const float* gathered, int world, int n_maps, int64_t n_max, int H, int W, int stripe_rows, float* full, iris_stream_t stream) {
+    if (world < 1 || n_maps < 0 || H < 0 || W < 0 || stripe_rows < 1 || n_max < 0) return fail(IRIS_ERR_ARG, "iris_unstripe_maps: bad arguments");
+    // the largest share of a rank: rank 0 owns stripes 0, world, 2 world, ...
+    const int n_stripes = (H + stripe_rows - 1) / stripe_rows;
+    int64_t rows0 = 0;
+    for (int s = 0; s < n_stripes; s += world) rows0 += std::min(stripe_rows, H - s * stripe_rows);
+    if (n_max < rows0 * W) return fail(IRIS_ERR_ARG, "iris_unstripe_maps: n_max is smaller than the largest rank's pixel count");
+    const int64_t total = (int64_t)H * W * n_maps * 3;
+    if (total == 0) return IRIS_OK;
+    if (!gathered || !full) return fail(IRIS_ERR_ARG, "iris_unstripe_maps: null pointer");
+    hipLaunchKernelGGL(unstripe_maps_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, gathered, world, n_maps, n_max, H, W, stripe_rows, full);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 // ---- the small helpers of utils/ops.py as calls of their own (inside the bake / path-tracing kernels the same device functions are fused)
 __global__ void normal_space_kernel(const float* normal, int64_t B, float* out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {

@@ -2,8 +2,9 @@
 
 Every (pixel, sample) is independent, so the path shards with no exchange inside it.  Rows are dealt to ranks in
 interleaved stripes (invalid pixels and deep-traversal regions spread evenly); each rank holds a full replica of the
-BVH / SLF / emitter tables and bakes only its pixels; ONE all_gather of the stacked maps (RCCL over xGMI on the GPU
-box, gloo in the CPU tests) followed by a local permutation rebuilds the image on every rank.  Sample streams are
+BVH / SLF / emitter tables and bakes only its pixels; ONE collective of the stacked maps (RCCL over xGMI on the GPU box, gloo in the
+CPU tests) -- a gather to the rank that writes the files, or an all_gather -- followed by one permutation pass rebuilds the image
+(MapGatherer).  Sample streams are
 keyed by the image-space pixel id, so the gathered image is bit-identical for every world size."""
 import torch
 import torch.distributed as dist
@@ -28,24 +29,64 @@ def max_local_pixels(H, W, world, stripe=STRIPE_ROWS):
     return max(int(stripe_rows(H, world, r, stripe).numel()) for r in range(world)) * W
 
 
-def gather_maps(local_maps, H, W, world, rank, stripe=STRIPE_ROWS, group=None):
-    """local_maps: (M, n_local, 3) rows in local_pixel_ids order -> (M, H*W, 3) full maps on every rank.
-    One collective: all_gather_into_tensor of equally padded buffers, then an index_copy per source rank."""
-    M, n_local, C = local_maps.shape
+class MapGatherer:
+    """The one collective of a sharded view, with everything it needs allocated ONCE per run (a 1080p view is 13 maps = 323 MB: the send
+    buffer, the receive buffer and the image-order output are reused for every view).
+
+      mode "gather"      dist.gather to rank 0 -- north_star's "single RCCL gather": only rank 0 (the rank that writes the files) receives, holds
+                         the receive / output buffers and runs the permutation; the other ranks' call returns None
+      mode "all_gather"  every rank ends with the full maps (what bench.py's cross-rank check and in-process consumers use)
+
+    The permutation back to image order is one pass: the HIP kernel iris_unstripe_maps for device tensors (pure index arithmetic, no index
+    tensors); host tensors (the gloo tests, whose per-rank compute is the oracle) use one cached index per source rank.
+    __call__(local_maps (M, n_local, 3) in local_pixel_ids order) -> (M, H*W, 3) or None.  The returned tensor is the gatherer's own buffer:
+    it is overwritten by the next call."""
+
+    def __init__(self, H, W, world, rank, n_maps, device, dtype=torch.float32, mode="all_gather", stripe=STRIPE_ROWS, group=None):
+        if mode not in ("gather", "all_gather"):
+            raise ValueError("mode must be 'gather' or 'all_gather'")
+        self.H, self.W, self.world, self.rank, self.M, self.stripe, self.group, self.mode = H, W, world, rank, n_maps, stripe, group, mode
+        self.device = torch.device(device)
+        self.n_local = int(stripe_rows(H, world, rank, stripe).numel()) * W
+        self.n_max = max_local_pixels(H, W, world, stripe)
+        self.receives = world > 1 and (mode == "all_gather" or rank == 0)
+        self.send = torch.zeros(n_maps, self.n_max, 3, device=self.device, dtype=dtype) if world > 1 else None
+        self.recv = torch.empty(world, n_maps, self.n_max, 3, device=self.device, dtype=dtype) if self.receives else None
+        self.full = torch.empty(n_maps, H * W, 3, device=self.device, dtype=dtype) if self.receives else None
+        self._ids = None          # host path: per-rank image pixel ids, built on first use
+
+    def __call__(self, local_maps):
+        if self.world == 1:
+            return local_maps
+        M, n_local, C = local_maps.shape
+        if (M, n_local, C) != (self.M, self.n_local, 3):
+            raise ValueError(f"MapGatherer: expected local maps of shape {(self.M, self.n_local, 3)}, got {tuple(local_maps.shape)}")
+        self.send[:, :n_local].copy_(local_maps)                 # (the padding rows stay zero)
+        backend = dist.get_backend(self.group)
+        if self.mode == "gather":
+            dst = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.gather(self.send, [self.recv[r] for r in range(self.world)] if self.rank == 0 else None, dst=dst, group=self.group)
+        elif backend == "gloo":
+            dist.all_gather([self.recv[r] for r in range(self.world)], self.send, group=self.group)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if not self.receives:
+            return None
+        if self.recv.is_cuda:
+            from . import _lib as L
+            with torch.cuda.device(self.recv.device):
+                L.check(L.lib().iris_unstripe_maps(L.ptr(self.recv), self.world, self.M, self.n_max, self.H, self.W, self.stripe, L.ptr(self.full), L.stream()))
+        else:
+            if self._ids is None:
+                self._ids = [local_pixel_ids(self.H, self.W, self.world, r, self.stripe) for r in range(self.world)]
+            for r, ids in enumerate(self._ids):
+                self.full.index_copy_(1, ids, self.recv[r, :, : ids.numel()])
+        return self.full
+
+
+def gather_maps(local_maps, H, W, world, rank, stripe=STRIPE_ROWS, group=None, mode="all_gather"):
+    """One-shot form of MapGatherer (allocates its buffers for this call; loops over views should keep a MapGatherer).
+    local_maps: (M, n_local, 3) rows in local_pixel_ids order -> (M, H*W, 3) full maps (mode "gather": on rank 0, None elsewhere)."""
     if world == 1:
         return local_maps
-    n_max = max_local_pixels(H, W, world, stripe)
-    buf = torch.zeros(M, n_max, C, device=local_maps.device, dtype=local_maps.dtype)
-    buf[:, :n_local] = local_maps
-    out = torch.empty(world, M, n_max, C, device=local_maps.device, dtype=local_maps.dtype)
-    if dist.get_backend(group) == "gloo":
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        out = torch.stack(parts)
-    else:
-        dist.all_gather_into_tensor(out, buf, group=group)
-    full = torch.zeros(M, H * W, C, device=local_maps.device, dtype=local_maps.dtype)
-    for r in range(world):
-        ids = local_pixel_ids(H, W, world, r, stripe, device=local_maps.device)
-        full.index_copy_(1, ids, out[r, :, : ids.numel()])
-    return full
+    return MapGatherer(H, W, world, rank, local_maps.shape[0], local_maps.device, local_maps.dtype, mode, stripe, group)(local_maps)

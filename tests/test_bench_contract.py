@@ -40,19 +40,53 @@ def test_single_gpu_line():
     assert d["multi_gpu"]["rccl_ranks_seen"] == 1 and d["multi_gpu"]["gather_ms"] is None
 
 
-@pytest.mark.timeout(900)
-def test_two_ranks_on_one_gpu_line():
+def _two_ranks(*extra, env_extra=None, expect_ok=True):
     """--gpus 2 as a plain command starts its own two workers; with IRIS_BENCH_BACKEND=gloo they may share the one GPU of this box
-    (a functional check of the N > 1 control flow: sharded bake, overlapped gather, cross-rank image check -- never a measurement)."""
-    env = dict(os.environ, IRIS_BENCH_BACKEND="gloo")
+    (a functional check of the N > 1 control flow -- never a measurement)."""
+    import time
+    env = dict(os.environ, IRIS_BENCH_BACKEND="gloo", **(env_extra or {}))
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "120", "--width", "160", "--spp", "32",
-           "--tris", "20000", "--slf-res", "64", "--views", "4", "--cpu-seconds", "0", "--no-extras", "--no-roofline"]
+           "--tris", "20000", "--slf-res", "64", "--views", "4", "--cpu-seconds", "0", "--no-extras", "--no-roofline"] + list(extra)
+    t0 = time.time()
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
+    dt = time.time() - t0
+    if not expect_ok:
+        return r, dt
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0]), dt
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("collective", ["gather", "all_gather"])
+def test_two_ranks_on_one_gpu_line(collective):
+    """sharded bake, overlapped gather (to rank 0: north_star's single gather; or to every rank), check of the gathered image against what was sent"""
+    d, _ = _two_ranks("--gather", collective)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     mg = d["multi_gpu"]
     assert mg["rccl_ranks_seen"] == 2 and len(mg["per_rank_ms_per_step"]) == 2 and mg["gather_ms"] is not None
-    assert mg["gather_overlapped"] is True and mg["gathered_image_identical_on_all_ranks"] is True
+    assert mg["gather_overlapped"] is True and mg["collective"] == collective and mg["gathered_image_matches_what_the_ranks_sent"] is True
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_sharded_by_views():
+    """SURVEY 8(e)'s fallback for the view sequence: whole views per rank, no collective, weak scaling"""
+    d, _ = _two_ranks("--shard", "views")
+    one, _ = _two_ranks("--shard", "views", "--steps", "1")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "no collective" in d["config"]["sharding"]
+    assert d["multi_gpu"]["gather_ms"] is None and d["multi_gpu"]["collective"] is None
+    rays_view = 120 * 160 * 32 * 7
+    assert 0.5 * 2 * rays_view < d["config"]["rays_per_step"] <= 2 * rays_view                # two whole views per step
+    assert one["config"]["rays_per_step"] == pytest.approx(d["config"]["rays_per_step"], rel=0.05)
+
+
+@pytest.mark.timeout(600)
+def test_a_rank_dying_mid_run_ends_the_job_quickly():
+    """rank 1 raises in its second step while rank 0 waits in the gather: bench.py --gpus 2 must exit non-zero within seconds, not hang"""
+    r, dt = _two_ranks(env_extra={"IRIS_BENCH_FAIL_RANK": "1", "IRIS_BENCH_FAIL_STEP": "1"}, expect_ok=False)
+    assert r.returncode != 0, r.stdout[-500:]
+    assert "IRIS_BENCH_FAIL_RANK" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]                 # no result line from a failed job
+    ok, dt_ok = _two_ranks()
+    assert dt < dt_ok + 30.0, (dt, dt_ok)                                                       # ended about as fast as a good run ends

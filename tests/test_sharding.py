@@ -42,6 +42,14 @@ def _worker(rank, world, port, q):
         a, b = oracle.bake(sc, em, pos, nrm, spp, wo=wo, roughness=0.412, seed=9, stream=3, pix_id=ids.astype(np.int32))
         local = torch.from_numpy(np.stack([Ld, a, b]))
         full = sh.gather_maps(local, H, W, world, rank, stripe=4)
+        # the persistent form, both collectives, buffers reused over "views": gather delivers to rank 0 only
+        ga = sh.MapGatherer(H, W, world, rank, 3, "cpu", mode="gather", stripe=4)
+        gb = sh.MapGatherer(H, W, world, rank, 3, "cpu", mode="all_gather", stripe=4)
+        for k in range(3):
+            fa, fb = ga(local * (k + 1)), gb(local * (k + 1))
+            assert (fa is None) == (rank != 0)
+            assert torch.equal(fb, full * (k + 1)) and (fa is None or torch.equal(fa, fb))
+            assert fb.data_ptr() == gb.full.data_ptr()           # no per-view allocation
         if rank == 0:
             q.put(full.numpy())
     finally:

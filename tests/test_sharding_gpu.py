@@ -52,6 +52,10 @@ def _worker(rank, world, port, tmp, q):
         ids = sh.local_pixel_ids(H, W, world, rank, stripe=8, device=dev)
         out = bs.bake_view(sc, em, xs[ids], ds[ids], SPP, [SPP] * 6, seed=5, pixel_ids=ids, image_width=W)
         full = sh.gather_maps(_maps(out), H, W, world, rank, stripe=8)
+        ga = sh.MapGatherer(H, W, world, rank, 13, dev, mode="gather", stripe=8)      # north_star's single gather: rank 0 alone receives
+        for k in range(2):
+            fa = ga(_maps(out))
+            assert (fa is None) == (rank != 0) and (fa is None or torch.equal(fa, full))
         if rank == 0:
             q.put(full.cpu().numpy())
     finally:
@@ -84,3 +88,20 @@ def test_two_rank_gpu_bake_equals_single_process(tmp_path):
     ref = _maps(bs.bake_view(sc, em, xs, ds, SPP, [SPP] * 6, seed=5, image_width=W)).cpu().numpy()
     assert ref.shape == (13, H * W, 3) and float(ref.sum()) > 0
     np.testing.assert_array_equal(full, ref)
+
+
+def test_unstripe_kernel_matches_index_copy():
+    """iris_unstripe_maps against the per-rank index_copy it replaces, ragged sizes included (H not a multiple of the stripe, more ranks than stripes)"""
+    from iris_amd import _lib as L, sharding as sh
+    dev = torch.device("cuda:0")
+    for Hh, Ww, world, stripe, M in [(1080, 1920, 8, 8, 2), (37, 11, 3, 4, 5), (5, 3, 8, 8, 1), (64, 64, 1, 8, 3)]:
+        n_max = sh.max_local_pixels(Hh, Ww, world, stripe)
+        recv = torch.randn(world, M, n_max, 3, device=dev)
+        ref = torch.zeros(M, Hh * Ww, 3, device=dev)
+        for r in range(world):
+            ids = sh.local_pixel_ids(Hh, Ww, world, r, stripe, device=dev)
+            ref.index_copy_(1, ids, recv[r, :, : ids.numel()])
+        out = torch.empty_like(ref)
+        L.check(L.lib().iris_unstripe_maps(L.ptr(recv), world, M, n_max, Hh, Ww, stripe, L.ptr(out), L.stream()))
+        assert torch.equal(out, ref)
+    assert L.lib().iris_unstripe_maps(L.ptr(recv), 1, 3, 10, 64, 64, 8, L.ptr(out), L.stream()) != 0      # n_max too small: an error, not a fault
