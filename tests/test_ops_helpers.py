@@ -92,10 +92,12 @@ def test_eval_diffuse_specular_compose_to_eval_brdf():
     np.testing.assert_array_equal(specular_sampler(u2, r, wo, n).cpu().numpy(), got[0].cpu().numpy())
 
 
-def test_raw_kernels_refuse_inputs_that_require_grad(dev):
+def test_raw_kernels_refuse_inputs_that_require_grad():
     """the reference's utils/ops.py helpers are differentiable torch ops; these are kernels without a backward pass and must say so instead
     of silently cutting the graph"""
     from iris_amd import _lib as L
+    from iris_amd.utils import ops
+    dev = torch.device("cuda:0")
     from iris_amd.model.brdf import BaseBRDF
     x = torch.rand(16, device=dev, requires_grad=True)
     n = torch.nn.functional.normalize(torch.randn(16, 3, device=dev), dim=-1)

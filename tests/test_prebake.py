@@ -1,6 +1,8 @@
 """the stages that write vslf.npz / emitter.pth (slf_bake.py:69-145, slf_refine.py:85-108,
-extract_emitter_ldr.py:72-115) run on the device and produce files the bake loads.  Oracle: numpy restatements of the reference
-lines over the same primary hits (the pooling primitives themselves are pinned by golden/slf_scatter.npz in test_gbuffer.py)."""
+extract_emitter_ldr.py:72-115) run on the device and produce files the bake loads.
+  test_drivers_vs_reference_replay: against tests/golden/prebake_box.npz -- the loop bodies of those scripts replayed through the reference's
+      own Python (VoxelSLF class, torch ops; tools/make_driver_goldens.py) on the rays and photographs stored in the fixture.
+  test_slf_bake_refine_and_emitter_extraction: a second, independent numpy restatement over views built here + the files load and bake."""
 import os
 
 import numpy as np
@@ -96,3 +98,42 @@ def test_slf_bake_refine_and_emitter_extraction(tmp_path):
     rays = views[0]["rays"]
     out = bs.bake_view(scene, emitter, rays[:, :3].contiguous(), rays[:, 3:].contiguous(), 16, [8] * 6, image_width=64)
     assert out["n_valid"] == rays.shape[0] and float(out["diffuse"].mean()) > 0.05
+
+
+def test_drivers_vs_reference_replay():
+    """bake_slf / refine_slf / extract_emitters against the reference's scripts replayed in its own Python (prebake_box.npz)"""
+    from iris_amd import slf_bake as sb
+    from iris_amd.utils.path_tracing import Scene
+    dev = torch.device("cuda:0")
+    g, f = golden("bake_box.npz"), golden("prebake_box.npz")
+    scene = Scene(g["verts"], g["faces"], device=dev)
+    views = [{"rays": torch.from_numpy(f[f"rays_{k}"]).to(dev), "rgbs": torch.from_numpy(f[f"rgbs_{k}"]).to(dev)} for k in range(int(f["n_views"]))]
+    res = int(f["res_spatial"])
+    # slf_bake.py:69-93: bounds (both dataset conventions)
+    lo, hi = sb.scene_bounds(scene, views, "synthetic", dev)
+    np.testing.assert_allclose([float(lo), float(hi)], f["bounds_synthetic"], rtol=1e-6, atol=1e-7)
+    sd = sb.bake_slf(scene, views, res_spatial=res, dataset="scannetpp", device=dev)
+    assert sd["voxel_min"] == pytest.approx(float(f["voxel_min"]), rel=1e-6, abs=1e-7) and sd["voxel_max"] == pytest.approx(float(f["voxel_max"]), rel=1e-6)
+    # :95-114 occupancy; :116-138 pooling through the reference's VoxelSLF
+    np.testing.assert_array_equal(sd["mask"].numpy(), f["mask"])
+    np.testing.assert_array_equal(sd["weight"]["inds"].numpy(), f["slf_inds"])
+    np.testing.assert_array_equal(sd["weight"]["count"].numpy(), f["slf_count"])
+    np.testing.assert_allclose(sd["weight"]["radiance"].numpy(), f["slf_radiance"], rtol=2e-5, atol=1e-6)       # (float sums: order of the atomics)
+    hist = sb.visible_voxels(scene, views, torch.tensor(sd["voxel_min"]), torch.tensor(sd["voxel_max"]), res, dev)
+    np.testing.assert_array_equal(hist.cpu().numpy(), f["hist"])
+    assert not any("_iris_hits" in b for b in views)                         # nothing stays pinned on the caller's batches
+    # slf_refine.py:90-106
+    for b in views:
+        b["rgbs"] = b["rgbs"] * 2
+    sd2 = sb.refine_slf(sd, scene, views, dev)
+    np.testing.assert_array_equal(sd2["weight"]["count"].numpy(), f["refined_count"])
+    np.testing.assert_allclose(sd2["weight"]["radiance"].numpy(), f["refined_radiance"], rtol=2e-5, atol=1e-6)
+    for b in views:
+        b["rgbs"] = b["rgbs"] / 2
+    # extract_emitter_ldr.py:77-115
+    em = sb.extract_emitters(scene, g["verts"], g["faces"], views, threshold=float(f["threshold"]), device=dev)
+    np.testing.assert_array_equal(em["is_emitter"].numpy(), f["is_emitter"])
+    np.testing.assert_array_equal(em["emitter_vertices"].numpy(), f["emitter_vertices"])
+    np.testing.assert_allclose(em["emitter_area"].numpy(), f["emitter_area"], rtol=1e-6)
+    np.testing.assert_allclose(em["emitter_normal"].numpy(), f["emitter_normal"], atol=1e-6)
+    assert em["emitter_radiance"].shape == (len(g["faces"]), 3) and float(em["emitter_radiance"].abs().sum()) == 0.0

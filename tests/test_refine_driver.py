@@ -1,6 +1,9 @@
 """The refine_shading driver (reference: refine_shading.py:99-177): per view the deterministic first hit, path_tracing_det_diff at spp 128 /
 indir_depth 5, path_tracing_det_spec for the six roughness levels at spp 64, every map denoised, the bake's 13 file names.  The integrators
-themselves are pinned to the reference's goldens in tests/test_refine.py; here the loop around them."""
+themselves are pinned to the reference's goldens in tests/test_refine.py; here the loop around them:
+  test_refine_view_vs_reference_replay  refine_view against the reference's two loops replayed in its own Python (tests/golden/refine_loop.npz)
+  test_refine_view_is_the_reference_loop  ragged multi-batch runs against the loop written out over this package's integrators (regression)
+  test_refine_cli_*                       the command line on a directory the bake CLI populated"""
 import json
 import os
 
@@ -13,6 +16,24 @@ from stub_material import StubMaterial
 from test_pt_single import _gpu_setup
 
 pytestmark = pytest.mark.gpu
+
+
+def test_refine_view_vs_reference_replay(tmp_path, oracle_mod):
+    """refine_shading.py:109-127 / :144-174 replayed through the reference's path_tracing_det_diff / _spec (tools/make_driver_goldens.py), every
+    torch.rand draw recorded per call; refine_view on the same rays with the same draws"""
+    from iris_amd import refine_shading as rs
+    from conftest import rel_l2
+    dev = torch.device("cuda:0")
+    f = golden("refine_loop.npz")
+    _, _, sc, em = _gpu_setup(tmp_path, dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    uniforms = {l: [[T(f[f"u_{l}_{c}_{k}"]) for k in range(int(f[f"n_u_{l}_{c}"]))] for c in range(int(f[f"n_calls_{l}"]))] for l in range(7)}
+    out = rs.refine_view(sc, em, StubMaterial(), T(f["rays_x"]), T(f["rays_d"]), int(f["spp_diffuse"]), int(f["spp_specular"]), int(f["indir_depth"]), uniforms=uniforms)
+    assert out["n_valid"] == int(f["valid"].sum())
+    assert rel_l2(out["diffuse"].cpu().numpy(), f["diffuse"]) <= 1e-4
+    for r in range(6):
+        assert rel_l2(out["specular0"][r].cpu().numpy(), f[f"specular0_{r}"]) <= 1e-4, r
+        assert rel_l2(out["specular1"][r].cpu().numpy(), f[f"specular1_{r}"]) <= 1e-4, r
 
 
 def test_refine_view_is_the_reference_loop(tmp_path):
