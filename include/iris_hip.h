@@ -70,6 +70,9 @@ IRIS_API int iris_scene_get_info(const iris_scene *, iris_scene_info *out);
  * vslf.npz (slf_bake.py:140-145); the denominator is float32(voxel_max - voxel_min) as in torch-CPU. */
 IRIS_API int iris_slf_create(const int64_t *inds, int H, const float *radiance, int64_t kv, double voxel_min, double voxel_max,
                     int device, iris_slf **out);
+/* the same from DEVICE buffers (inds int64 (H,H,H), radiance (kv,3) on `device`): the pre-bake stages build the grid on the GPU (slf_bake.py:116-118) */
+IRIS_API int iris_slf_create_dev(const int64_t *inds_dev, int H, const float *radiance_dev, int64_t kv, double voxel_min, double voxel_max,
+                    int device, iris_slf **out, iris_stream_t);
 /* refresh the radiance rows from a DEVICE pointer (kv,3): mean pooling rewrites them (slf_bake.py:138, slf_refine.py:106) */
 IRIS_API int iris_slf_set_radiance(iris_slf *, const float *radiance_dev, int64_t kv, iris_stream_t);
 IRIS_API void iris_slf_destroy(iris_slf *);

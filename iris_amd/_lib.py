@@ -30,6 +30,7 @@ PROTOTYPES = {
     "iris_scene_destroy": [_P],
     "iris_scene_get_info": [_P, C.POINTER(SceneInfo)],
     "iris_slf_create": [_P, _I32, _P, _I64, _D, _D, _I32, C.POINTER(_P)],
+    "iris_slf_create_dev": [_P, _I32, _P, _I64, _D, _D, _I32, C.POINTER(_P), _P],
     "iris_slf_set_radiance": [_P, _P, _I64, _P],
     "iris_slf_destroy": [_P],
     "iris_emitter_create": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, C.POINTER(_P)],

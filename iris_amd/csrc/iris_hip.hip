@@ -261,6 +261,44 @@ extern "C" IRIS_API int iris_slf_create(const int64_t* inds, int H, const float*
     return IRIS_OK;
     API_END
 }
+// The same from DEVICE buffers (the pre-bake stages build the grid on the GPU: slf_bake.py:116-118 constructs VoxelSLF from the occupancy mask it has
+// just counted there): no 8 H^3-byte round trip through the host.  One 4-byte read-back reports an out-of-range entry.
+__global__ void slf_inds_narrow_kernel(const int64_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n, int64_t kv, int* __restrict__ bad) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = src[i];
+        if (v < -1 || v >= kv) *bad = 1;
+        dst[i] = (int32_t)v;
+    }
+}
+__global__ void pad_rows_kernel(const float* __restrict__ src, float4* __restrict__ dst, int64_t n);
+extern "C" IRIS_API int iris_slf_create_dev(const int64_t* inds_dev, int H, const float* radiance_dev, int64_t kv, double voxel_min, double voxel_max,
+                                   int device, iris_slf** out, iris_stream_t stream) {
+    API_BEGIN
+    if (!out || !inds_dev || H <= 0 || H > 1024 || kv < 0 || (kv > 0 && !radiance_dev)) return fail(IRIS_ERR_ARG, "iris_slf_create_dev: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)H * H * H;
+    iris_slf* s = new iris_slf();
+    s->device = device; s->kv = kv;
+    int* d_bad = nullptr;
+    auto cleanup = [&](int rc, const char* msg) { (void)hipFree(s->d_inds); (void)hipFree(s->d_rad); (void)hipFree(d_bad); delete s; return fail(rc, msg); };
+    if (hipMalloc(&s->d_inds, n * 4) != hipSuccess || hipMalloc(&s->d_rad, (size_t)std::max<int64_t>(kv, 1) * 16) != hipSuccess || hipMalloc(&d_bad, 4) != hipSuccess)
+        return cleanup(IRIS_ERR_HIP, "iris_slf_create_dev: out of device memory");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(d_bad, 0, 4, st);
+    (void)hipMemsetAsync(s->d_rad, 0, (size_t)std::max<int64_t>(kv, 1) * 16, st);
+    hipLaunchKernelGGL(slf_inds_narrow_kernel, dim3(grid_for((int64_t)n, 256, 8192)), dim3(256), 0, st, inds_dev, (int32_t*)s->d_inds, (int64_t)n, kv, d_bad);
+    if (kv > 0) hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(kv, 256, 1024)), dim3(256), 0, st, radiance_dev, (float4*)s->d_rad, kv);
+    int bad = 0;
+    if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return cleanup(IRIS_ERR_HIP, "iris_slf_create_dev: HIP error");
+    if (bad) return cleanup(IRIS_ERR_ARG, "iris_slf_create_dev: inds entry out of range");
+    (void)hipFree(d_bad);
+    s->dev.inds = (const int32_t*)s->d_inds; s->dev.radiance = (const float4*)s->d_rad; s->dev.H = H;
+    s->dev.vmin = (float)voxel_min;
+    s->dev.den = (float)(voxel_max - voxel_min);
+    *out = s;
+    return IRIS_OK;
+    API_END
+}
 extern "C" IRIS_API void iris_slf_destroy(iris_slf* s) {
     if (!s) return;
     (void)hipFree(s->d_inds); (void)hipFree(s->d_rad);

@@ -17,12 +17,15 @@ class VoxelSLF(nn.Module):
         self.H = H
         self.voxel_min = float(voxel_min)
         self.voxel_max = float(voxel_max)
+        # (the buffers are built where the mask lives: a mask counted on the GPU -- slf_bake -- never visits the host; the reference builds on the CPU)
+        mask = torch.as_tensor(mask)
+        dev = mask.device
         kk, jj, ii = torch.where(mask)
-        inds = -torch.ones(H, H, H, dtype=torch.long)
-        inds[kk, jj, ii] = torch.arange(len(ii))
+        inds = -torch.ones(H, H, H, dtype=torch.long, device=dev)
+        inds[kk, jj, ii] = torch.arange(len(ii), device=dev)
         self.register_buffer("inds", inds)
-        self.register_buffer("radiance", torch.zeros(len(ii), 3))
-        self.register_buffer("count", torch.zeros(len(ii), dtype=torch.long))
+        self.register_buffer("radiance", torch.zeros(len(ii), 3, device=dev))
+        self.register_buffer("count", torch.zeros(len(ii), dtype=torch.long, device=dev))
         self._h = None
         self._h_device = None
         self._ver = None
@@ -54,11 +57,18 @@ class VoxelSLF(nn.Module):
         iv = self._tver(self.inds)
         if self._h is None or self._h_device != device or not self._same(self._ver, iv):
             self.refresh()
-            inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
-            rad = L.host_f32(self.radiance).reshape(-1, 3)
             h = C.c_void_p()
-            L.check(L.lib().iris_slf_create(inds.ctypes.data_as(C.c_void_p), self.H, rad.ctypes.data_as(C.c_void_p), rad.shape[0],
-                                            self.voxel_min, self.voxel_max, device.index or 0, C.byref(h)))
+            on_dev = lambda t: t.is_cuda and t.device.index == (device.index if device.index is not None else torch.cuda.current_device())
+            if device.type == "cuda" and on_dev(self.inds) and on_dev(self.radiance):
+                inds = self.inds.detach().to(torch.int64).contiguous()
+                rad = self.radiance.detach().to(torch.float32).contiguous().reshape(-1, 3)
+                with torch.cuda.device(device):
+                    L.check(L.lib().iris_slf_create_dev(L.ptr(inds), self.H, L.ptr(rad), rad.shape[0], self.voxel_min, self.voxel_max, device.index or 0, C.byref(h), L.stream()))
+            else:
+                inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
+                rad = L.host_f32(self.radiance).reshape(-1, 3)
+                L.check(L.lib().iris_slf_create(inds.ctypes.data_as(C.c_void_p), self.H, rad.ctypes.data_as(C.c_void_p), rad.shape[0],
+                                                self.voxel_min, self.voxel_max, device.index or 0, C.byref(h)))
             self._h, self._h_device, self._ver, self._rver = h, device, iv, self._tver(self.radiance)
         elif need_radiance and not self._same(self._rver, self._tver(self.radiance)):
             rr = self.radiance.detach().to(device=device, dtype=torch.float32).contiguous()

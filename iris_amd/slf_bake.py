@@ -96,7 +96,7 @@ def bake_slf(scene, views, res_spatial=256, dataset="scannetpp", device="cuda"):
         voxel_min, voxel_max = scene_bounds(scene, views, dataset, device, cache=True)
         hist = visible_voxels(scene, views, voxel_min, voxel_max, res_spatial, device, cache=True)
         mask = hist > 0
-        vslf = VoxelSLF(mask.cpu(), voxel_min.item(), voxel_max.item())
+        vslf = VoxelSLF(mask, voxel_min.item(), voxel_max.item())            # index grid and buffers built on the device the mask was counted on
         vslf = pool_radiance(scene, views, vslf, device, cache=True)
     finally:
         drop_hits(views)

@@ -66,3 +66,23 @@ def test_tiny_far_nodes_do_not_lose_rays(dev, oracle_mod):
     _, _, _, oidx, ovalid = osc.ray_intersect(o, d, brute=True)
     np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
     np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), ovalid.astype(bool))
+
+
+def test_voxel_slf_built_on_the_device_and_rebound_buffers(dev):
+    """(i) a VoxelSLF constructed from a mask that lives on the GPU (slf_bake counts the occupancy there) builds its index grid and its device
+    tables without visiting the host and answers like the one built on the CPU; (ii) ADVICE round 2: a REBOUND radiance buffer
+    (`vslf.radiance = vslf.radiance / n`, fresh tensors start at _version 0 and may reuse a freed address) is picked up."""
+    from iris_amd.model.slf import VoxelSLF
+    torch.manual_seed(0)
+    H = 32
+    mask = torch.rand(H, H, H) < 0.3
+    a = VoxelSLF(mask, -0.2, 3.1)                   # host buffers (the reference's way)
+    b = VoxelSLF(mask.to(dev), -0.2, 3.1)           # device buffers
+    assert b.inds.is_cuda and torch.equal(a.inds, b.inds.cpu())
+    rad = torch.rand(a.radiance.shape[0], 3)
+    a.radiance[:] = rad; b.radiance[:] = rad.to(dev)
+    x = (torch.rand(20000, 3, device=dev) * 3.6 - 0.4)
+    assert torch.equal(a.spatial_idx(x), b.spatial_idx(x)) and torch.equal(a(x)["rgb"], b(x)["rgb"])
+    for k in range(6):                              # rebinding in a loop: freed addresses come back, versions restart at 0
+        b.radiance = b.radiance / 2.0
+        assert torch.equal(b(x)["rgb"], a(x)["rgb"] / 2.0 ** (k + 1))
