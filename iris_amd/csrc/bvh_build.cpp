@@ -175,7 +175,7 @@ float sah_of(const Node2* nodes, int32_t i, float root_area) {
 }  // namespace
 
 WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces, int64_t nf, int width, int leaf_tris,
-                       float pad_rel, float tri_cost, float presplit, bool pair_quads) {
+                       float pad_rel, float tri_cost, float presplit) {
     leaf_tris = std::min(7, std::max(1, leaf_tris));
     WideBvh out;
     out.width = width;
@@ -206,52 +206,6 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
     const float pad = pad_rel * ext + 1e-30f;
     out.pad = pad;
 
-    // ---- quad pairing: two triangles stored as (a,b,c) and (a,c,d) -- what a triangulated quad looks like in most mesh files -- become ONE
-    // primitive (and one 64-B leaf record with the four vertices): the tree is built over half as many primitives, and the leaf test projects
-    // four vertices and evaluates five edge functions for the two triangles instead of six and six.  Only this vertex pattern is paired,
-    // because each triangle keeps ITS stored vertex order (the barycentric roles, and with them the bits of u, v and of the hit point, depend
-    // on it).  Triangles long enough to be split below stay single; so do pairs whose joint box is not clearly smaller than the two boxes apart.
-    std::vector<uint8_t> absorbed;
-    if (pair_quads && nf >= 2) {
-        out.pair.assign((size_t)nf, -1);
-        absorbed.assign((size_t)nf, 0);
-        float limit = kInf;
-        if (presplit > 0.f) {
-            std::vector<float> sorted((size_t)nf);
-            for (int64_t f = 0; f < nf; ++f) { const Box& b = tri[(size_t)f].b; sorted[(size_t)f] = std::max({b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}); }
-            std::vector<float> side(sorted);
-            std::nth_element(sorted.begin(), sorted.begin() + nf / 2, sorted.end());
-            limit = presplit * sorted[(size_t)(nf / 2)];
-            if (!(limit > 0.f)) limit = kInf;
-            for (int64_t f = 0; f < nf; ++f) if (side[(size_t)f] > limit) absorbed[(size_t)f] = 2;      // (2: will be split -> never paired)
-        }
-        std::vector<std::pair<uint64_t, int32_t>> key((size_t)nf);        // (first vertex, second vertex) -> triangle
-        for (int64_t f = 0; f < nf; ++f) key[(size_t)f] = {((uint64_t)(uint32_t)faces[f * 3] << 32) | (uint32_t)faces[f * 3 + 1], (int32_t)f};
-        std::sort(key.begin(), key.end());
-        for (int64_t f = 0; f < nf; ++f) {
-            if (absorbed[(size_t)f]) continue;
-            const int32_t a = faces[f * 3], b = faces[f * 3 + 1], c = faces[f * 3 + 2];
-            if (a == b || b == c || a == c) continue;
-            const uint64_t want = ((uint64_t)(uint32_t)a << 32) | (uint32_t)c;
-            for (auto it = std::lower_bound(key.begin(), key.end(), std::make_pair(want, (int32_t)-1)); it != key.end() && it->first == want; ++it) {
-                const int32_t g = it->second;
-                if (g == (int32_t)f || absorbed[(size_t)g] || out.pair[(size_t)g] >= 0) continue;
-                const int32_t d = faces[(int64_t)g * 3 + 2];
-                if (d == a || d == b || d == c) continue;
-                Box u = tri[(size_t)f].b; u.grow(tri[(size_t)g].b);
-                if (u.area() > 0.85f * (tri[(size_t)f].b.area() + tri[(size_t)g].b.area())) continue;
-                out.pair[(size_t)f] = g; absorbed[(size_t)g] = 1;
-                tri[(size_t)f].b = u;
-                for (int k = 0; k < 3; ++k) tri[(size_t)f].c[k] = 0.5f * (u.lo[k] + u.hi[k]);
-                break;
-            }
-        }
-        // the absorbed second triangles leave the primitive list
-        size_t m = 0;
-        for (int64_t f = 0; f < nf; ++f) if (absorbed[(size_t)f] != 1) order[m++] = (int32_t)f;
-        order.resize(m);
-    }
-
     // ---- early split clipping: a triangle much longer than the typical one (decimated walls and floors next to fine detail) is
     // referenced through several boxes, each the bounds of the triangle clipped to a piece of its box, so that it does not force one
     // large leaf box across everything beside it.  A reference whose longest side exceeds presplit x (median longest side) is cut at the
@@ -269,8 +223,7 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
         if (limit > 0.f) {
             struct Cand { float side; int32_t ref; bool operator<(const Cand& o) const { return side < o.side || (side == o.side && ref > o.ref); } };
             std::vector<Cand> heap;
-            for (int64_t f = 0; f < nf; ++f)
-                if (side[(size_t)f] > limit && !(!absorbed.empty() && (absorbed[(size_t)f] == 1 || out.pair[(size_t)f] >= 0))) heap.push_back({side[(size_t)f], (int32_t)f});   // (pairs are never split)
+            for (int64_t f = 0; f < nf; ++f) if (side[(size_t)f] > limit) heap.push_back({side[(size_t)f], (int32_t)f});
             if (!heap.empty()) {
                 std::make_heap(heap.begin(), heap.end());
                 ref_tri.resize((size_t)nf);
@@ -301,11 +254,11 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
             }
         }
     }
-    const int64_t nref = (int64_t)order.size();      // primitives: single triangles, pairs, references of split triangles
+    const int64_t nref = (int64_t)tri.size();
 
     std::vector<Node2> nodes((size_t)(2 * nref));
     Builder bld;
-    bld.tri = tri.data(); bld.order = order.data(); bld.nodes = nodes.data(); bld.max_leaf = 0;   // down to single primitives
+    bld.tri = tri.data(); bld.order = order.data(); bld.nodes = nodes.data(); bld.max_leaf = 0;   // down to single triangles
     bld.build(0, (int32_t)nref, 0);
     for (int k = 0; k < 3; ++k) { out.root_lo[k] = nodes[0].b.lo[k] - pad; out.root_hi[k] = nodes[0].b.hi[k] + pad; }
 

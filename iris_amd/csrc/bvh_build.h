@@ -20,11 +20,8 @@ struct WideNode {
 struct WideBvh {
     int width = 0;
     std::vector<WideNode> nodes;     // nodes[0] is the root; the internal children of a node are consecutive
-    std::vector<int32_t> tri_order;  // leaf order -> original triangle index; a node's leaf records are consecutive.  A triangle split into
-                                     // several references (presplit) appears once per reference; the first triangle A of a PAIR stands for both
-    std::vector<int32_t> pair;       // (pair_quads) per triangle: its partner B when the triangle is the first of a pair, else -1.  A pair is two
-                                     // triangles stored as (a,b,c) and (a,c,d): one leaf record holds the four vertices, and the watertight test
-                                     // projects each of them once (iris_trace.h quad_test)
+    std::vector<int32_t> tri_order;  // leaf order -> original triangle index; a node's leaf triangles are consecutive.  Longer than the mesh
+                                     // when long triangles were split into several references (presplit): those appear once per reference
     float root_lo[3], root_hi[3];
     int depth = 0;
     float sah_cost = 0.f;
@@ -34,9 +31,9 @@ struct WideBvh {
 // verts: (nv,3) f32, faces: (nf,3) i32.  leaf_tris: max triangles per leaf (1..7).  tri_cost: cost of one triangle test relative to
 // one wide-node visit in the SAH the collapse minimises (measured on the traversal kernels: ~70 against ~110 instructions).
 // Boxes are padded by `pad_rel * max(|coordinate|, extent)` so that the f32 slab test is conservative with respect to the
-// triangle test (see DESIGN.md "closest-hit semantics").  presplit: early split clipping of triangles whose box is longer than
+// Moeller-Trumbore test (see DESIGN.md "closest-hit semantics").  presplit: early split clipping of triangles whose box is longer than
 // presplit x the median triangle's (0 = off), see bvh_build.cpp.
 WideBvh build_wide_bvh(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int width, int leaf_tris,
-                       float pad_rel = 2e-5f, float tri_cost = 0.7f, float presplit = 8.f, bool pair_quads = false);
+                       float pad_rel = 2e-5f, float tri_cost = 0.7f, float presplit = 8.f);
 
 }  // namespace iris

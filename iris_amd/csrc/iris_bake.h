@@ -253,10 +253,10 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
                 f3 pn = mk3(0.f, 0.f, 0.f);
                 int64_t tri = -1;
                 if (h.slot >= 0) {
-                    f3 v0, v1, v2; int tid;
-                    hit_triangle(a.sc, h.slot, v0, v1, v2, tid);
-                    pn = hit_position(h, v0, v1, v2);
-                    tri = tid;
+                    const float4* tr = a.sc.tris + (int64_t)h.slot * 4;
+                    const float4 tx = tr[0], ty = tr[1], tz = tr[2];      // component-major record (iris_trace.h)
+                    pn = hit_position(h, mk3(tx.x, ty.x, tz.x), mk3(tx.y, ty.y, tz.y), mk3(tx.z, ty.z, tz.z));
+                    tri = __float_as_int(tx.w);
                 }
                 if (a.tri_next) a.tri_next[(p0 + pl) * spp + s] = tri;
                 float epdf; bool vn; int src;

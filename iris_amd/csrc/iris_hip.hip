@@ -123,12 +123,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     if (g_opt_bvh_max_leaf > 0) max_leaf = (int)std::min<long long>(7, g_opt_bvh_max_leaf);   // iris_debug_set("bvh_max_leaf")
     const float tri_cost = g_opt_bvh_tri_cost_x100 > 0 ? (float)g_opt_bvh_tri_cost_x100 * 0.01f : 0.7f;   // iris_debug_set("bvh_tri_cost_x100")
     const float presplit = g_opt_bvh_presplit_x10 >= 0 ? (float)g_opt_bvh_presplit_x10 * 0.1f : 8.f;       // iris_debug_set("bvh_presplit_x10"); 0 = off
-#ifndef IRIS_NO_QUADS
-    const bool pair_quads = true;
-#else
-    const bool pair_quads = false;
-#endif
-    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit, pair_quads);
+    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit);
     if (bvh.tri_order.size() >= (size_t)(1 << 26) - 1) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^26 leaf records");
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
 
@@ -193,22 +188,19 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
             for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }
     }
-    // ---- encode leaf records (64 B, one per 64-B line), component-major so that the watertight test's axis permutation is an address offset:
-    // (q0.x,q1.x,q2.x,q3.x) (q0.y,..) (q0.z,..) (idA, idB, 0, 0).  Triangle A = (q0,q1,q2) = tri_order[i] in its stored vertex order; a paired
-    // triangle B = (q0,q2,q3) likewise; a single triangle repeats q1 as q3 and has idB = -1 (csrc/iris_trace.h quad_test) ----
+    // ---- encode leaf triangles (64 B, one per 64-B line), component-major so that the watertight test's axis permutation is an address
+    // offset: (p0.x, p1.x, p2.x, id) (p0.y, p1.y, p2.y, id) (p0.z, p1.z, p2.z, id) (0, 0, 0, 0) ----
     const size_t nt = bvh.tri_order.size();
-    std::vector<float> tris((nt + 1) * 16, 0.f);      // + the degenerate record unused child slots point to (ids -1, never accepted: det = 0)
-    { const int32_t none = -1; std::memcpy(&tris[nt * 16 + 12], &none, 4); std::memcpy(&tris[nt * 16 + 13], &none, 4); }
+    std::vector<float> tris((nt + 1) * 16, 0.f);      // + the degenerate record unused child slots point to (id -1, never accepted: det = 0)
+    { const int32_t none = -1; for (int k = 0; k < 3; ++k) std::memcpy(&tris[nt * 16 + 4 * k + 3], &none, 4); }
     for (size_t i = 0; i < nt; ++i) {
-        const int32_t fa = bvh.tri_order[i];
-        const int32_t fb = bvh.pair.empty() ? -1 : bvh.pair[(size_t)fa];
+        int32_t f = bvh.tri_order[i];
         float* p = tris.data() + i * 16;
-        const int32_t q[4] = {faces[(int64_t)fa * 3], faces[(int64_t)fa * 3 + 1], faces[(int64_t)fa * 3 + 2], fb >= 0 ? faces[(int64_t)fb * 3 + 2] : faces[(int64_t)fa * 3 + 1]};
-        for (int v = 0; v < 4; ++v) {
-            const float* pv = verts + (int64_t)q[v] * 3;
+        for (int v = 0; v < 3; ++v) {
+            const float* pv = verts + (int64_t)faces[(int64_t)f * 3 + v] * 3;
             for (int k = 0; k < 3; ++k) p[4 * k + v] = pv[k];
         }
-        std::memcpy(&p[12], &fa, 4); std::memcpy(&p[13], &fb, 4);
+        for (int k = 0; k < 3; ++k) std::memcpy(&p[4 * k + 3], &f, 4);
     }
     iris_scene* s = new iris_scene();
     s->device = device;

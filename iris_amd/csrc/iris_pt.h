@@ -111,6 +111,14 @@ __device__ __forceinline__ Mat load_mat(const PtArgs& a, int64_t i) {
     return m;
 }
 
+// hit triangle of a leaf slot: vertices + original triangle index
+__device__ __forceinline__ void hit_triangle(const SceneDev& sc, int slot, f3& p0, f3& p1, f3& p2, int& id) {
+    const float4* r = sc.tris + (int64_t)slot * 4;
+    const float4 X = r[0], Y = r[1], Z = r[2];      // component-major record (iris_trace.h)
+    p0 = mk3(X.x, Y.x, Z.x); p1 = mk3(X.y, Y.y, Z.y); p2 = mk3(X.z, Y.z, Z.z);
+    id = __float_as_int(X.w);
+}
+
 // utils/path_tracing.py:357-382: emitter sampling, visibility ray, geometry term, eval_brdf, power-2 MIS.
 // term1 = coef1 * radiance[e1]   (e1 = -1 -> no contribution)
 // everything after the visibility ray: (slot, u, v) = its closest hit (slot < 0: miss)

@@ -14,7 +14,7 @@ constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
 // Scene as laid out in HBM
 struct SceneDev {
     const float4* nodes;  // layout-dependent; BVH4_F32: 8 x float4 = 128 B per node, 128-B aligned
-    const float4* tris;   // 64-B leaf records (one L2 half-line), component-major: (q0.x,q1.x,q2.x,q3.x) (q0.y,..) (q0.z,..) (idA,idB,0,0): one or two triangles (quad_test)
+    const float4* tris;   // 64 B per leaf triangle (one L2 half-line), component-major: (p0.x,p1.x,p2.x,id) (p0.y,p1.y,p2.y,id) (p0.z,p1.z,p2.z,id) (0,0,0,0)
     int n_nodes;
     int n_tris;
     int phase_min;  // wave-level phase scheduling threshold (see trace_bvh4)
@@ -23,7 +23,7 @@ struct SceneDev {
 
 struct Hit {
     float t, u, v;
-    int slot;  // 2 * leaf record + (0: its triangle A, 1: its triangle B), -1 = miss
+    int slot;  // index into SceneDev::tris, -1 = miss
     int id;    // original triangle index
 };
 
@@ -68,9 +68,8 @@ struct Stack {
 // three 2-D edge functions are evaluated with plain products and a plain difference: rnd(a*b) - rnd(c*d) is exactly antisymmetric in the two
 // vertices (the two triangles sharing an edge see opposite values) and never has the opposite sign of the exact value; a value of 0 is
 // re-evaluated in double (exact sign).  So no ray can slip between two triangles that share an edge or a vertex.
-// The axis permutation costs nothing here: a leaf record stores its vertices component-major -- (q0.x,q1.x,q2.x,q3.x) (q0.y,..) (q0.z,..) -- and a
+// The axis permutation costs nothing here: a leaf record stores the triangle component-major -- (p0.x,p1.x,p2.x,id) (p0.y,..) (p0.z,..) -- and a
 // lane reads plane kx / ky / kz by ADDRESS (three 16-B loads from one 64-B line either way).  Arithmetic contract of oracle/iris_oracle.c.
-// (records: see quad_test)
 struct RayXf {
     float ox, oy, oz;   // origin, permuted: o[kx], o[ky], o[kz]
     float sx, sy, sz;   // shear: d[kx] * sz, d[ky] * sz, sz = 1 / d[kz]
@@ -89,74 +88,34 @@ __device__ __forceinline__ void ray_xform(f3 o, f3 d, RayXf& x) {
     x.offx = kx << 4; x.offy = ky << 4; x.offz = kz << 4;
 }
 
-// One triangle from its projected vertices (A, B, C in the triangle's stored order), the contract of oracle/iris_oracle.c tri_test: accept iff the
-// edge functions have no two strictly opposite signs, det = U + V + W != 0 and 0 <= t < inf; (b1, b2) = (V, W) / det (p = b0 p0 + b1 p1 + b2 p2),
-// t = (U Az + V Bz + W Cz) * sz / det (z = P[kz] - o[kz]).  `slot` = 2 * leaf record + (0 | 1): which triangle of the record.
-__device__ __forceinline__ void tri_finish(float U, float V, float W, float Az, float Bz, float Cz, float sz, bool inside, int id, int slot, Hit& h) {
-    const float det = (U + V) + W;
-    const float inv_det = 1.0f / det;
-    const float t = (fmaf(U, Az, fmaf(V, Bz, W * Cz)) * sz) * inv_det;
-    const float u = V * inv_det, v = W * inv_det;
-    // det == 0 gives t = NaN or +-inf: a NaN fails every comparison, and +inf can only tie with the initial h.t, whose h.id = INT_MIN no index is smaller than
-    const bool ok = inside && t >= 0.f;
-    // closest hit = lexicographic min of (t, original index)
-    if (ok && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
-}
-__device__ __forceinline__ bool same_side(float U, float V, float W) { return !(fminf(fminf(U, V), W) < 0.f && fmaxf(fmaxf(U, V), W) > 0.f); }
-// exact re-evaluation of a triangle's three edge functions (A, B, C projected vertices)
-__device__ __forceinline__ void edges_exact(float Ax, float Ay, float Bx, float By, float Cx, float Cy, float& U, float& V, float& W) {
-    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
-}
-
-// The test on leaf record `rec` = (q0.x,q1.x,q2.x,q3.x) (q0.y,..) (q0.z,..) (idA, idB, -, -): triangle A = (q0,q1,q2) and, when idB >= 0, triangle
-// B = (q0,q2,q3), each in ITS stored vertex order (a single triangle has q3 = q1 and idB = -1).  The four vertices are projected once, and the
-// edge function of B along the diagonal is the exact negative of A's (antisymmetry), so a pair costs 4 projections + 5 edge functions + ONE
-// division instead of 6 + 6 + 2; per triangle the arithmetic -- and every bit of the result -- is that of the single-triangle contract
-// (oracle/iris_oracle.c tri_test): a triangle with an edge function that comes out 0 has its three re-evaluated exactly; then the sign test;
-// then t, u, v.  Both triangles passing (a folded quad, or the ray exactly through the diagonal) is the rare second trip of the loop.
-__device__ __forceinline__ void quad_test(const SceneDev& sc, int rec, const RayXf& x, Hit& h) {
-    const uint32_t base = (uint32_t)rec << 6;      // 32-bit byte offset from the (scalar) table base
+// The test on leaf record `slot`.  Accept iff the edge functions have no two strictly opposite signs, det = U + V + W != 0 and 0 <= t < inf;
+// (b1, b2) = (V, W) / det (p = b0 p0 + b1 p1 + b2 p2), t = (U Az + V Bz + W Cz) * sz / det (z = P[kz] - o[kz]).
+__device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const RayXf& x, Hit& h) {
+    const uint32_t base = (uint32_t)slot << 6;     // 32-bit byte offset from the (scalar) table base
     const char* tb = reinterpret_cast<const char*>(sc.tris);
     const float4 X = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offx));
     const float4 Y = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offy));
     const float4 Z = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offz));
-    const int2 ids = *reinterpret_cast<const int2*>(tb + (size_t)(base + 48u));
-    const float z0 = Z.x - x.oz, z1 = Z.y - x.oz, z2 = Z.z - x.oz, z3 = Z.w - x.oz;
-    const float x0 = fmaf(-x.sx, z0, X.x - x.ox), y0 = fmaf(-x.sy, z0, Y.x - x.oy);
-    const float x1 = fmaf(-x.sx, z1, X.y - x.ox), y1 = fmaf(-x.sy, z1, Y.y - x.oy);
-    const float x2 = fmaf(-x.sx, z2, X.z - x.ox), y2 = fmaf(-x.sy, z2, Y.z - x.oy);
-    const float x3 = fmaf(-x.sx, z3, X.w - x.ox), y3 = fmaf(-x.sy, z3, Y.w - x.oy);
-    float UA = x2 * y1 - y2 * x1, VA = x0 * y2 - y0 * x2, WA = x1 * y0 - y1 * x0;       // A = (q0, q1, q2): U = f(C, B), V = f(A, C), W = f(B, A)
-    float UB = x3 * y2 - y3 * x2, VB = x0 * y3 - y0 * x3, WB = -VA;                     // B = (q0, q2, q3); f(q2, q0) = -f(q0, q2) exactly
-    if (fminf(fminf(fminf(fabsf(UA), fabsf(VA)), fabsf(WA)), fminf(fabsf(UB), fabsf(VB))) == 0.f) {      // (rare: the ray through an edge or a vertex, or an underflow)
-        const bool zA = fminf(fminf(fabsf(UA), fabsf(VA)), fabsf(WA)) == 0.f, zB = fminf(fminf(fabsf(UB), fabsf(VB)), fabsf(WB)) == 0.f;
-        float u, v, w;
-        edges_exact(x0, y0, x1, y1, x2, y2, u, v, w);
-        if (zA) { UA = u; VA = v; WA = w; }
-        edges_exact(x0, y0, x2, y2, x3, y3, u, v, w);
-        if (zB) { UB = u; VB = v; WB = w; }
+    const int id = __float_as_int(Z.w);            // (every plane carries the index)
+    const float Atz = Z.x - x.oz, Btz = Z.y - x.oz, Ctz = Z.z - x.oz;
+    const float Ax = fmaf(-x.sx, Atz, X.x - x.ox), Ay = fmaf(-x.sy, Atz, Y.x - x.oy);
+    const float Bx = fmaf(-x.sx, Btz, X.y - x.ox), By = fmaf(-x.sy, Btz, Y.y - x.oy);
+    const float Cx = fmaf(-x.sx, Ctz, X.z - x.ox), Cy = fmaf(-x.sy, Ctz, Y.z - x.oy);
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (fminf(fminf(fabsf(U), fabsf(V)), fabsf(W)) == 0.f) {      // any of them 0 (rare: the ray through an edge or a vertex of the projected triangle, or an underflow)
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
     }
-    const bool inA = same_side(UA, VA, WA), inB = ids.y >= 0 && same_side(UB, VB, WB);
-    bool sel = !inA;                                                                      // the triangle to finish: A if it passes, else B
-#pragma unroll 1
-    for (;;) {
-        tri_finish(sel ? UB : UA, sel ? VB : VA, sel ? WB : WA, z0, sel ? z2 : z1, sel ? z3 : z2, x.sz, sel ? inB : inA, sel ? ids.y : ids.x, rec * 2 + (sel ? 1 : 0), h);
-        if (sel || !inB) break;
-        sel = true;                                                                       // both pass: B as well
-    }
-}
-// vertices (stored order) and original index of the triangle a hit refers to
-__device__ __forceinline__ void hit_triangle(const SceneDev& sc, int slot, f3& p0, f3& p1, f3& p2, int& id) {
-    const float4* r = sc.tris + (int64_t)(slot >> 1) * 4;
-    const float4 X = r[0], Y = r[1], Z = r[2];
-    const int2 ids = *reinterpret_cast<const int2*>(r + 3);
-    const bool b = slot & 1;
-    p0 = mk3(X.x, Y.x, Z.x);
-    p1 = b ? mk3(X.z, Y.z, Z.z) : mk3(X.y, Y.y, Z.y);
-    p2 = b ? mk3(X.w, Y.w, Z.w) : mk3(X.z, Y.z, Z.z);
-    id = b ? ids.y : ids.x;
+    const float det = (U + V) + W;
+    const float inv_det = 1.0f / det;
+    const float t = (fmaf(U, Atz, fmaf(V, Btz, W * Ctz)) * x.sz) * inv_det;
+    const float u = V * inv_det, v = W * inv_det;
+    // no two edge functions of strictly opposite sign; det == 0 gives t = NaN or +-inf: a NaN fails every comparison, and +inf can only tie with the
+    // initial h.t, whose h.id = INT_MIN no index is smaller than
+    const bool ok = !(fminf(fminf(U, V), W) < 0.f && fmaxf(fmaxf(U, V), W) > 0.f) && t >= 0.f;
+    // closest hit = lexicographic min of (t, original index)
+    if (ok && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -290,7 +249,7 @@ __device__ __forceinline__ RayXf leaf_phase_xform(const RayState& r) {
 }
 template <class STACK>
 __device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, const RayXf& xf, STACK& st) {
-    quad_test(sc, (int)((r.cur & 0x7fffffffu) >> 3), xf, r.h);
+    tri_test(sc, (int)((r.cur & 0x7fffffffu) >> 3), xf, r.h);
     r.cur += 7u;                                                  // leaf ref = leafbit | start << 3 | count: start + 1, count - 1
     if ((r.cur & 7u) == 0u) r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
 }
@@ -424,8 +383,9 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
 // Mitsuba Mesh::compute_surface_interaction restated: p = fma(p0,b0,fma(p1,b1,p2*b2)), b0 = (1-b1)-b2;
 // n = normalize(cross(p1-p0,p2-p0)).
 __device__ __forceinline__ void hit_vertices(const SceneDev& sc, const Hit& h, f3& p0, f3& p1, f3& p2) {
-    int id;
-    hit_triangle(sc, h.slot, p0, p1, p2, id);
+    const float4* r = sc.tris + (int64_t)h.slot * 4;
+    float4 X = r[0], Y = r[1], Z = r[2];      // component-major: (p0.x,p1.x,p2.x,id) (p0.y,...) (p0.z,...)
+    p0 = mk3(X.x, Y.x, Z.x); p1 = mk3(X.y, Y.y, Z.y); p2 = mk3(X.z, Y.z, Z.z);
 }
 __device__ __forceinline__ f3 hit_position(const Hit& h, f3 p0, f3 p1, f3 p2) {
     float b1 = h.u, b2 = h.v, b0 = (1.f - b1) - b2;
