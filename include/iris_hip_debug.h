@@ -41,7 +41,7 @@ IRIS_API int iris_debug_bake_specular(const iris_scene *, const iris_emitter *, 
  *   "bvh_max_leaf" 1..7 (4)      "bvh_tri_cost_x100": SAH cost of a triangle test relative to a node visit, in % (70)
  *   "bvh_presplit_x10": triangles whose box is longer than this many tenths of the median triangle's are referenced through several
  *                       clipped boxes (80; 0 = off)
- *   "phase_min" lanes (16)      "tile_target_rays" (5120)      "tiles_per_block" (4)
+ *   "phase_min" lanes (12)      "tile_target_rays" (4096)      "tiles_per_block" (4)
  *   "pt_tile_min": smallest batch the path-tracing stages route through the tile-sorted kernel
  * NOT thread-safe: plain process-wide globals that iris_scene_create / the launches read.  Set them before creating handles, from one thread. */
 IRIS_API int iris_debug_set(const char *key, long long value);

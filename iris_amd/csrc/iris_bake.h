@@ -210,6 +210,22 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
     const uint32_t spp_m = spp > 1 ? (uint32_t)(0x100000000ull / (uint64_t)(uint32_t)spp) + 1u : 0u;
     auto div_spp = [&](int r) -> int { return spp > 1 ? (int)__umulhi((uint32_t)r, spp_m) : r; };
 
+    // The tangent frame of a pixel (utils/ops.py:12-30: a cross product, a normalisation with its square root and three divisions) is the same for
+    // all of its spp samples: computed once per pixel into the part of the stack region the sort does not use (room for kFramePx pixels, i.e. every
+    // tile of spp >= 40), instead of once per ray in phase A.  Same function, same bits.
+    constexpr int kFrameOff = (kTileRays + 2 * 256 * 4) / 4, kFramePx = (TILE_STACK * kBlock - kFrameOff) / 6;
+    float* s_frames = reinterpret_cast<float*>(s_stack) + kFrameOff;
+    const bool frames = np <= kFramePx;
+    if (frames) {
+        for (int pl = tid; pl < np; pl += kBlock) {
+            f3 t, b;
+            normal_space(ld3(a.nrm + (p0 + pl) * 3), t, b);
+            float* f = s_frames + pl * 6;
+            f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = b.x; f[4] = b.y; f[5] = b.z;
+        }
+        __syncthreads();
+    }
+
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
     tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
         a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
@@ -219,7 +235,8 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, long long tile, flo
             const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
             const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
             f3 t, b;
-            normal_space(n, t, b);
+            if (frames) { const float* f = s_frames + pl * 6; t = mk3(f[0], f[1], f[2]); b = mk3(f[3], f[4], f[5]); }
+            else normal_space(n, t, b);
             f3 wi; float g0, g1;
             sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
             res[r] = make_float4(wi.x, wi.y, wi.z, 0.f);

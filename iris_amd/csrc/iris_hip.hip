@@ -802,9 +802,12 @@ extern "C" IRIS_API int iris_philox_u2(uint64_t seed, uint64_t idx0, uint32_t st
 // Pixels per tile.  ~5000-ray tiles are the optimum at 1080p x SPP 128 (with 32-B slots: 8192 rays: 324 ms per view, 6144: 322, 5120: 319,
 // 4096: 308, 3072: 314, 2048: 326; with today's 24-B slots 4096: 6.99, 5120: 7.04, 6144: 6.98 Grays/s): larger tiles push the workgroups' slot
 // slabs out of the 256 MB Infinity Cache, smaller ones pay more low-utilisation drains (one per wave and tile).  The LDS ray list is sized for
-// exactly that (kTileRays = 5120), which is what lets 7 workgroups share a CU.  iris_debug_set("tile_target_rays") overrides downwards.
+// exactly that (kTileRays = 5120), which is what lets 7 workgroups share a CU.  Round 3 (watertight leaf test, phase threshold 12): 3072-ray tiles
+// 7.37, 3584: 7.42, 4096: 7.50, 4608: 7.45, 5120: 7.43 Grays/s -> the default target is 4096 (spp above it still get kTileRays).
+// iris_debug_set("tile_target_rays") overrides.
+constexpr int kTileTarget = 4096;
 static int tile_pixels(int spp) {
-    const int target = g_opt_tile_target_rays > 0 ? (int)std::min<long long>(kTileRays, std::max<long long>(64, g_opt_tile_target_rays)) : kTileRays;
+    const int target = g_opt_tile_target_rays > 0 ? (int)std::min<long long>(kTileRays, std::max<long long>(64, g_opt_tile_target_rays)) : kTileTarget;
     return std::max(1, std::min(kTileRays, std::max(target, spp)) / spp);
 }
 static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)

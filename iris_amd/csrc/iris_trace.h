@@ -148,7 +148,7 @@ __device__ __forceinline__ bool first_active_lane() {
 // or done.  The wave alternates a NODE phase and a LEAF phase; a phase ends when no lane needs it, or early when fewer than
 // kPhaseMin lanes still need it while at least kPhaseMin lanes wait for the other phase (stragglers are carried over instead of
 // keeping the whole wave in a nearly empty phase).  Per-lane results do not depend on the schedule.
-constexpr int kPhaseMin = 16;
+constexpr int kPhaseMin = 12;      // (round 3 sweep at 4096-ray tiles: 10: 7.47, 12: 7.50, 14: 7.50, 16: 7.47, 20: 7.32 Grays/s)
 
 // Node layouts (iris_hip.h): BVH4_F32 = 128-B node with f32 planes (7 dwordx4 per visit); BVH4_Q8 = 64-B node
 // {origin.xyz, scale.x | scale.y, scale.z, qlo_x, qlo_y | qlo_z, qhi_x, qhi_y, qhi_z | ref[4]} with 8-bit planes relative to the node's
