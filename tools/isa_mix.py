@@ -27,7 +27,7 @@ def main():
     src = os.path.join(REPO, "iris_amd", "csrc", "iris_hip.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
                "-I" + os.path.join(REPO, "include"), "-S", "--cuda-device-only", "-o", out, src] + args.extra.split()
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         lines = open(out).read().splitlines()

@@ -7,7 +7,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--kernel", default="bake_view_k
 a = ap.parse_args()
 with tempfile.TemporaryDirectory() as tmp:
     out = a.dump or os.path.join(tmp, "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-I" + os.path.join(REPO, "include"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I" + os.path.join(REPO, "include"),
                            "-S", "--cuda-device-only", "-o", out, os.path.join(REPO, "iris_amd", "csrc", "iris_hip.hip")] + a.extra.split(), stderr=subprocess.DEVNULL)
     lines = open(out).read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4iris\d+" + re.escape(a.kernel) + r".*:\s*(;.*)?$", l))
