@@ -226,7 +226,7 @@ def main():
                 e1.record(); ev_view.append((e0, e1, rays))
             pending = list(zip(lobes, res))
         else:
-            ls = bs.LobeStreams(dev, args.streams)
+            ls = bs.LobeStreams(dev, args.streams, emitter)
             pending = []
             for l in lobes:
                 if l == 0:

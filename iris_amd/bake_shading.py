@@ -137,8 +137,12 @@ class LobeStreams:
     kernel (its last tiles) overlaps with the head of the next instead of idling the chip; `join()` makes the caller's stream
     wait for all of them.  With n=1 everything stays on the caller's stream."""
 
-    def __init__(self, device, n=3):
+    def __init__(self, device, n=3, emitter=None):
         self.main = torch.cuda.current_stream(device)
+        if emitter is not None:
+            # a pending re-upload of the radiance tables (in-place edit, load_state_dict) happens HERE, on the caller's stream, which every side
+            # stream waits for -- not inside the first lobe's side stream, where the other lobes' kernels would not be ordered after it
+            emitter.handle(device); emitter.slf.handle(device)
         self.side = [torch.cuda.Stream(device=device) for _ in range(n)] if n > 1 else []
         self.k = 0
 
@@ -202,7 +206,7 @@ def bake_view(scene, emitter, xs, ds, spp_diffuse=SPP_DIFFUSE, spps_specular=Non
                          seed=seed, stream_ids=want, pix_id=g["pix_id"])
         pending = list(zip(want, res))
     else:
-        ls = LobeStreams(dev, n_streams)
+        ls = LobeStreams(dev, n_streams, emitter)
         pending = []
         for l in want:
             if l == 0:
