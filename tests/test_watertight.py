@@ -104,3 +104,61 @@ def test_hip_is_watertight_and_equals_oracle(oracle_mod):
     np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
     np.testing.assert_array_equal(pos.cpu().numpy(), p)
     np.testing.assert_array_equal(uv.cpu().numpy(), ouv)
+
+
+def _icosphere(subdiv=4, seed=11, noise=0.08):
+    """closed, consistently indexed triangle mesh: a subdivided icosahedron with radial noise (shared vertices are shared by INDEX and value)"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]; v.append(p / np.linalg.norm(p)); mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    v = np.asarray(v)
+    rng = np.random.default_rng(seed)
+    r = 1.0 + noise * rng.standard_normal(len(v))
+    return (v * r[:, None] * 1.7 + np.array([0.3, -0.2, 0.9])).astype(np.float32), np.asarray(f, np.int32)
+
+
+def _interior_rays(n, seed=13):
+    rng = np.random.default_rng(seed)
+    o = (rng.standard_normal((n, 3)) * 0.25 + np.array([0.3, -0.2, 0.9])).astype(np.float32)      # well inside (radius >= 1.7 * (1 - 4 sigma))
+    d = rng.standard_normal((n, 3)); d[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], (n // 8, 1))   # some axis-parallel
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return np.ascontiguousarray(o), np.ascontiguousarray(d)
+
+
+def test_oracle_closed_mesh_never_leaks(oracle_mod):
+    """every ray from inside a closed surface hits it -- the property a watertight test + a conservative BVH guarantee together"""
+    v, f = _icosphere()
+    o, d = _interior_rays(400_000)
+    sc = oracle_mod.Scene(v, f)
+    _, _, _, idx, valid = sc.ray_intersect(o, d)
+    assert valid.all(), f"{(~valid).sum()} of {len(valid)} rays left a closed mesh"
+
+
+@pytest.mark.gpu
+def test_hip_closed_mesh_never_leaks(oracle_mod):
+    import torch
+    from iris_amd.utils.path_tracing import Scene, ray_intersect
+    dev = torch.device("cuda:0")
+    v, f = _icosphere(subdiv=5)                    # 20 480 triangles
+    o, d = _interior_rays(4_000_000)
+    sc = Scene(v, f, device=dev)
+    pos, nrm, uv, idx, valid = ray_intersect(sc, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))
+    assert bool(valid.all()), f"{int((~valid).sum())} of {len(o)} rays left a closed mesh"
+    sel = np.arange(0, len(o), 40)
+    p, _, ouv, oidx, _ = oracle_mod.Scene(v, f).ray_intersect(o[sel], d[sel])
+    np.testing.assert_array_equal(idx.cpu().numpy()[sel], oidx)
+    np.testing.assert_array_equal(pos.cpu().numpy()[sel], p)
