@@ -192,15 +192,20 @@ class _PtAccumulate(torch.autograd.Function):
         return (g.to(rad_dev),) + (None,) * 9
 
 
-def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, uniforms=None):
+def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, uniforms=None, compact=None):
     """Path trace the scene with one bounce and power-2 MIS (utils/path_tracing.py:320-407).
 
     Args as the reference: rays_o, rays_d, dx_du, dy_dv Bx3; spp samples per pixel.  material_net(position) returns
     {'albedo','roughness','metallic'} (the reference's NGPBRDF; any callable works).  uniforms: optional list of the five
     draws the reference makes, [rand(2,B,spp,1), rand(N), rand(N,2), rand(N), rand(N,2)] (parity mode).
+    compact: True = compact the paths that continue after the primary hit, as the reference does (its draws are sized by that count, so this is
+    the mode of the parity fixtures; costs two host synchronisations per call); False = keep all B*spp paths in place and mask the ones that do
+    not continue (missed / emitter primary hits: a per-cent of the rays) -- the same per-path arithmetic and the same sum order, no host
+    synchronisation anywhere in the call, which is what a training loop of 262 144-ray calls is bound by; None = False when the draws are this
+    function's own (uniforms is None), True otherwise.
     Returns L Bx3, differentiable with respect to emitter_net.radiance.
     """
-    return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, 0, uniforms)
+    return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, 0, uniforms, compact=compact)
 
 
 def path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms=None):
@@ -213,13 +218,17 @@ def path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv,
     return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, int(indir_depth), uniforms, full=True)
 
 
-def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, full=False):
+def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, full=False, compact=None):
     rays_o = L.require_gpu(rays_o, torch.float32, "rays_o").reshape(-1, 3)
     rays_d = L.require_gpu(rays_d, torch.float32, "rays_d").reshape(-1, 3)
     dx_du = L.require_gpu(dx_du, torch.float32, "dx_du").reshape(-1, 3)
     dy_dv = L.require_gpu(dy_dv, torch.float32, "dy_dv").reshape(-1, 3)
     B, dev = rays_o.shape[0], rays_o.device
     lib = L.lib()
+    if compact is None:
+        compact = uniforms is not None or full
+    if full and not compact:
+        raise L.IrisError("path_tracing: the continuation (trace_indirect) compacts its paths; compact=False is for path_tracing_single")
     u = list(uniforms) if uniforms is not None else None
     nxt = (lambda *shape: L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(*shape)) if u is not None else (lambda *shape: torch.rand(*shape, device=dev))
 
@@ -234,16 +243,22 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         L.check(lib.iris_pt_primary_emit(eh, L.ptr(triangle_idx), B * spp, L.ptr(e0), L.ptr(valid_next), L.stream()))
         radiance = emitter_net.radiance
 
-        if not bool(valid_next.any()):          # the reference returns the un-reduced (B*spp,3) tensor here (:347-348)
-            rdev = radiance.to(device=dev)
-            ext = torch.cat([rdev, rdev.new_zeros(1, 3)])
-            return ext[torch.where(e0 >= 0, e0.long(), torch.full_like(e0, radiance.shape[0]).long())]
-
-        sel = torch.nonzero(valid_next, as_tuple=False).reshape(-1)
-        N = sel.numel()
-        path_of = torch.full((B * spp,), -1, device=dev, dtype=torch.int32)
-        path_of[sel] = torch.arange(N, device=dev, dtype=torch.int32)
-        position, normal, wo = position[sel].contiguous(), normal[sel].contiguous(), (-wi[sel]).contiguous()
+        if compact:
+            if not bool(valid_next.any()):          # the reference returns the un-reduced (B*spp,3) tensor here (:347-348)
+                rdev = radiance.to(device=dev)
+                ext = torch.cat([rdev, rdev.new_zeros(1, 3)])
+                return ext[torch.where(e0 >= 0, e0.long(), torch.full_like(e0, radiance.shape[0]).long())]
+            sel = torch.nonzero(valid_next, as_tuple=False).reshape(-1)
+            N = sel.numel()
+            path_of = torch.full((B * spp,), -1, device=dev, dtype=torch.int32)
+            path_of[sel] = torch.arange(N, device=dev, dtype=torch.int32)
+            position, normal, wo = position[sel].contiguous(), normal[sel].contiguous(), (-wi[sel]).contiguous()
+        else:
+            # every path stays at its ray's index; the ones that do not continue keep path_of = -1 and are ignored by the accumulation (their stage
+            # outputs are computed on the zeros ray_intersect returns for a miss, or on the emitter hit, and never read)
+            N = B * spp
+            path_of = torch.where(valid_next, torch.arange(N, device=dev, dtype=torch.int32), torch.full((N,), -1, device=dev, dtype=torch.int32))
+            wo = -wi
 
         mat = material_net(position)
         albedo = mat["albedo"].detach().to(torch.float32).reshape(-1, 3).contiguous()

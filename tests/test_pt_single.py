@@ -122,6 +122,25 @@ def test_hip_path_tracing_single_forward_backward(tmp_path, oracle_mod):
         oL, terms = oracle_mod.path_tracing_single(osc, oem, stub_material_np, p["rays_o"], p["rays_d"], p["dx_du"], p["dy_dv"], int(p["spp"]),
                                                    [p[f"u{k}"] for k in range(5)], radiance=p["radiance"])
     np.testing.assert_array_equal(L.detach().cpu().numpy(), oL)
+    # the un-compacted mode (no host synchronisation: what a training loop runs): with the reference's draws moved to their rays' indices it is
+    # the same arithmetic in the same order -- the forward pass bit for bit
+    from iris_amd import _lib as Lb
+    from iris_amd.utils.path_tracing import ray_intersect
+    B, spp = p["rays_o"].shape[0], int(p["spp"])
+    wi0 = torch.empty(B * spp, 3, device=dev)
+    rd, dxu, dyv, ro, dudv = T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]), T(p["rays_o"]), unif[0].reshape(2, B, spp).contiguous()      # (kept alive across the launch)
+    Lb.check(Lb.lib().iris_pt_jitter(Lb.ptr(rd), Lb.ptr(dxu), Lb.ptr(dyv), Lb.ptr(dudv), B, spp, Lb.ptr(wi0), Lb.stream()))
+    _, _, _, tri0, _ = ray_intersect(sc, ro.repeat_interleave(spp, 0), wi0)
+    e0 = torch.empty(B * spp, device=dev, dtype=torch.int32); vn = torch.empty(B * spp, device=dev, dtype=torch.bool)
+    Lb.check(Lb.lib().iris_pt_primary_emit(em.handle(dev), Lb.ptr(tri0), B * spp, Lb.ptr(e0), Lb.ptr(vn), Lb.stream()))
+    assert int(vn.sum()) == unif[1].numel() and 0 < int(vn.sum()) < B * spp
+    wide = [unif[0]]
+    for k in (1, 2, 3, 4):
+        w = torch.full((B * spp,) + tuple(unif[k].shape[1:]), 0.25, device=dev); w[vn] = unif[k]; wide.append(w)
+    Lm = path_tracing_single(sc, em, StubMaterial(), T(p["rays_o"]), T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]), spp, uniforms=wide, compact=False)
+    assert torch.equal(Lm.detach(), L.detach())
+    (gm,) = torch.autograd.grad((Lm * T(p["grad_weight"])).sum(), em.radiance)
+    assert rel_l2(gm.cpu().numpy(), gr.cpu().numpy()) <= 1e-6                 # (a scatter of float atomics: equal up to summation order)
     # random draws path (no uniforms given): finite, deterministic shape, gradient reaches only emitter rows
     torch.manual_seed(0)
     L2 = path_tracing_single(sc, em, StubMaterial(), T(p["rays_o"]), T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]), 8)
