@@ -165,6 +165,17 @@ def ray_intersect(scene, xs, ds):
 # ----------------------------------------------------------------------------------------------------------------------
 # cfg 5: the one-bounce MIS path tracer the reference trains through (utils/path_tracing.py:320-407)
 # ----------------------------------------------------------------------------------------------------------------------
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """one extra HIP stream per device for stages that are independent of each other"""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 class _PtAccumulate(torch.autograd.Function):
     """L = mean_spp(radiance[e0] + coef1*radiance[e1] + coef2*radiance[e2] + const2): gather forward, scatter-add backward.
     Only emitter.radiance receives gradient; geometry and sampled directions carry none."""
@@ -265,11 +276,17 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         rough = mat["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
         metal = mat["metallic"].detach().to(torch.float32).reshape(-1).contiguous()
 
-        # direct illumination: emitter sampling + MIS (:357-382)
+        # direct illumination: emitter sampling + MIS (:357-382).  Independent of the BRDF-sampling branch below: launched on a side stream, so that
+        # its visibility rays run beside the (longer) BRDF rays -- at 262 144 paths per call either kernel alone leaves most of the chip idle
         s1, s2 = nxt(N), nxt(N, 2)
         coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
-        L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
-                                L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 0.0 if full else 1e-6, L.stream()))
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        fork = torch.cuda.Event(); fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
+                                    L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 0.0 if full else 1e-6, L.stream()))
+            join = torch.cuda.Event(); join.record(side)
         # BRDF sampling + next intersection (:384-391)
         s1b, s2b = nxt(N), nxt(N, 2)
         wi_b = torch.empty(N, 3, device=dev); pdf_b = torch.empty(N, device=dev); w_b = torch.empty(N, 3, device=dev)
@@ -284,6 +301,7 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         hit_valid = torch.empty(N, device=dev, dtype=torch.bool) if full else None
         L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi_b), L.ptr(tri_n), L.ptr(rough_n), L.ptr(pdf_b), L.ptr(w_b), N,
                                         L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(hit_valid) if full else None, 0.6 if full else 0.0, 1e-6, L.stream()))
+        main.wait_event(join)              # (before anything frees or reads the tensors the side stream works on)
         if full and indir_depth > 0:
             keep = torch.nonzero(hit_valid, as_tuple=False).reshape(-1)
             L_indir = trace_indirect(scene, emitter_net, material_net, pos_n[keep].contiguous(), (-wi_b[keep]).contiguous(), nrm_n[keep].contiguous(), indir_depth,
