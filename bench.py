@@ -414,6 +414,13 @@ def main():
             rl.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
         result["roofline"] = rl
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (before the CPU baseline: its OpenMP team keeps spinning for a while after the last parallel region, and this loop of small launches is
+        #  bound by the host thread that issues them -- on a box whose cgroup grants exactly as many CPUs as that team has threads)
+        # ---- extras: BASELINE configs[4] (train_brdf_crf / train_emitter inner loop: differentiable one-bounce path tracer, SPP 32) on the same scene
+        from tools import bench_pt_single
+        result["extras"] = {"cfg5_path_tracing_single": bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2)}
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----
         import oracle
@@ -469,11 +476,6 @@ def main():
                                   "calibration_mrays_per_s_by_threads": calib,
                                   "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, OpenMP x{threads}"}
         result["gpu_over_cpu"] = round(value / (n / dtc / 1e6), 1)
-
-    if rank == 0 and world == 1 and not args.no_extras:
-        # ---- extras: BASELINE configs[4] (train_brdf_crf / train_emitter inner loop: differentiable one-bounce path tracer, SPP 32) on the same scene
-        from tools import bench_pt_single
-        result["extras"] = {"cfg5_path_tracing_single": bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2)}
 
     if rank == 0:
         print(json.dumps(result), flush=True)
