@@ -36,7 +36,6 @@ struct Node2 {
     int32_t left = -1, right = -1;  // internal
     int32_t start = 0, count = 0;   // leaf if count > 0
     int32_t first = 0, ntri = 0;    // the subtree's triangles: order[first, first + ntri)
-    int8_t axis = 0;                // split axis (the left child holds the lower centroids)
 };
 
 struct Builder {
@@ -122,7 +121,7 @@ struct Builder {
             r = build(mid, start + count - mid, depth + 1);
         }
         Node2& nd2 = nodes[me];
-        nd2.left = l; nd2.right = r; nd2.count = 0; nd2.axis = (int8_t)std::max(best_axis, 0);
+        nd2.left = l; nd2.right = r; nd2.count = 0;
         return me;
     }
 };
@@ -176,7 +175,7 @@ float sah_of(const Node2* nodes, int32_t i, float root_area) {
 }  // namespace
 
 WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces, int64_t nf, int width, int leaf_tris,
-                       float pad_rel, float tri_cost, float presplit, bool balanced) {
+                       float pad_rel, float tri_cost, float presplit) {
     leaf_tris = std::min(7, std::max(1, leaf_tris));
     WideBvh out;
     out.width = width;
@@ -320,29 +319,11 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
         out.depth = std::max(out.depth, it.depth);
         ch.clear();
         const Node2& r = nodes[(size_t)it.n2];
-        uint8_t tab[3] = {0, 0, 0};
         if (r.count > 0 || (it.n2 == 0 && dp[0].leaf)) ch.push_back({it.n2, true});      // a root that is itself a leaf: one leaf child
-        else if (balanced) {
-            static const uint8_t kAxisTab[3] = {0xAA, 0xCC, 0xF0};                        // octants whose direction is negative along x / y / z
-            auto is_leaf = [&](int32_t c) { return nodes[(size_t)c].count > 0 || dp[(size_t)c].leaf != 0; };
-            tab[0] = kAxisTab[r.axis];
-            const int32_t side[2] = {r.left, r.right};
-            for (int g = 0; g < 2; ++g) {
-                const int32_t c = side[g];
-                if (is_leaf(c)) { ch.push_back({c, true}); ch.push_back({-1, true}); }      // (-1: unused slot)
-                else {
-                    tab[1 + g] = kAxisTab[nodes[(size_t)c].axis];
-                    ch.push_back({nodes[(size_t)c].left, is_leaf(nodes[(size_t)c].left)});
-                    ch.push_back({nodes[(size_t)c].right, is_leaf(nodes[(size_t)c].right)});
-                }
-            }
-        }
         else { emit(emit, r.left, dp[(size_t)it.n2].k[W], ch); emit(emit, r.right, W - dp[(size_t)it.n2].k[W], ch); }
         WideNode w = empty_node();
         w.n = (int)ch.size();
-        for (int k = 0; k < 3; ++k) w.order_tab[k] = tab[k];
         for (int i = 0; i < w.n; ++i) {          // internal children first get consecutive wide indices
-            if (ch[(size_t)i].n2 < 0) continue;  // unused slot (balanced collapse): stays the empty child
             const Node2& c = nodes[(size_t)ch[(size_t)i].n2];
             for (int k = 0; k < 3; ++k) { w.lo[i][k] = c.b.lo[k] - pad; w.hi[i][k] = c.b.hi[k] + pad; }
             if (!ch[(size_t)i].leaf) {
@@ -352,7 +333,6 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
             }
         }
         for (int i = 0; i < w.n; ++i) {
-            if (ch[(size_t)i].n2 < 0) continue;
             const Node2& c = nodes[(size_t)ch[(size_t)i].n2];
             if (ch[(size_t)i].leaf) {
                 w.child[i] = -1;

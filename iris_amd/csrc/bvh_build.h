@@ -15,8 +15,6 @@ struct WideNode {
     int32_t child[kMaxWidth];        // >=0: index of an internal wide node; -1: leaf
     int32_t leaf_start[kMaxWidth];   // leaf: first triangle in tri_order
     int32_t leaf_count[kMaxWidth];   // leaf: number of triangles
-    uint8_t order_tab[3] = {0, 0, 0}; // (balanced collapse) per ray octant (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0) one bit each: visit slots {2,3} before
-                                     // {0,1} / slot 1 before 0 / slot 3 before 2 -- the order of the binary splits the node was collapsed from
 };
 
 struct WideBvh {
@@ -36,8 +34,6 @@ struct WideBvh {
 // Moeller-Trumbore test (see DESIGN.md "closest-hit semantics").  presplit: early split clipping of triangles whose box is longer than
 // presplit x the median triangle's (0 = off), see bvh_build.cpp.
 WideBvh build_wide_bvh(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int width, int leaf_tris,
-                       float pad_rel = 2e-5f, float tri_cost = 0.7f, float presplit = 8.f, bool balanced = false);
-// balanced: every wide node is a binary node with its two children expanded once -- slots {0,1} = the left child's children (or the left child itself when it is
-// a leaf), {2,3} the right one's; unused slots have child = -1 and leaf_count = 0 -- so that the front-to-back order follows from the three split axes (order_tab).
+                       float pad_rel = 2e-5f, float tri_cost = 0.7f, float presplit = 8.f);
 
 }  // namespace iris

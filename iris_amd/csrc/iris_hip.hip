@@ -123,12 +123,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     if (g_opt_bvh_max_leaf > 0) max_leaf = (int)std::min<long long>(7, g_opt_bvh_max_leaf);   // iris_debug_set("bvh_max_leaf")
     const float tri_cost = g_opt_bvh_tri_cost_x100 > 0 ? (float)g_opt_bvh_tri_cost_x100 * 0.01f : 0.7f;   // iris_debug_set("bvh_tri_cost_x100")
     const float presplit = g_opt_bvh_presplit_x10 >= 0 ? (float)g_opt_bvh_presplit_x10 * 0.1f : 8.f;       // iris_debug_set("bvh_presplit_x10"); 0 = off
-#ifdef IRIS_OCTANT_ORDER
-    const bool balanced = true;
-#else
-    const bool balanced = false;
-#endif
-    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit, balanced);
+    WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit);
     if (bvh.tri_order.size() >= (size_t)(1 << 26) - 1) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^26 leaf records");
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
 
@@ -139,7 +134,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     // to the triangle table (all zeros: det = 0, never accepted), never kEmptyRef, which the traversal also uses as "lane idle".
     const uint32_t dummy_leaf = kLeafBit | ((uint32_t)bvh.tri_order.size() << 3) | 1u;
     auto child_ref = [&](const WideNode& w, int s) -> uint32_t {
-        if (s >= w.n || (w.child[s] < 0 && w.leaf_count[s] == 0)) return dummy_leaf;
+        if (s >= w.n) return dummy_leaf;
         if (w.child[s] >= 0) return (uint32_t)w.child[s];
         return kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
     };
@@ -161,23 +156,20 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
             float org[3], hi3[3];
             for (int k = 0; k < 3; ++k) {
                 org[k] = INFINITY; hi3[k] = -INFINITY;
-                for (int s = 0; s < w.n; ++s) { if (w.child[s] < 0 && w.leaf_count[s] == 0) continue; org[k] = std::min(org[k], w.lo[s][k]); hi3[k] = std::max(hi3[k], w.hi[s][k]); }
-                if (!(org[k] <= hi3[k])) { org[k] = 0.f; hi3[k] = 0.f; }
+                for (int s = 0; s < w.n; ++s) { org[k] = std::min(org[k], w.lo[s][k]); hi3[k] = std::max(hi3[k], w.hi[s][k]); }
+                if (w.n == 0) { org[k] = 0.f; hi3[k] = 0.f; }
             }
-            float scale_f[3];
+            uint32_t ebytes = 0;
             uint8_t q[6][4];   // planes lo_x lo_y lo_z hi_x hi_y hi_z
             for (int k = 0; k < 3; ++k) {
                 const double ext = (double)hi3[k] - (double)org[k];
                 int e = -126;
                 if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
                 while (std::ldexp(255.0, e) < ext) ++e;                       // 255 * 2^e must cover the extent
-                // (IRIS_OCTANT_ORDER: the low mantissa byte of the stored scale carries order_tab[k]; the planes are quantised against that value)
-                float scf = std::ldexp(1.0f, e + 24);
-                { uint32_t bits; std::memcpy(&bits, &scf, 4); bits |= (uint32_t)w.order_tab[k]; std::memcpy(&scf, &bits, 4); }
-                scale_f[k] = scf;
-                const double sc = std::ldexp((double)scf, -24);
+                const double sc = std::ldexp(1.0, e);
+                ebytes |= (uint32_t)(e + 127) << (8 * k);
                 for (int s = 0; s < 4; ++s) {
-                    if (s >= w.n || (w.child[s] < 0 && w.leaf_count[s] == 0)) { q[k][s] = 255; q[3 + k][s] = 0; continue; }   // inverted box: never hit
+                    if (s >= w.n) { q[k][s] = 255; q[3 + k][s] = 0; continue; }   // inverted box: never hit
                     int lo = (int)std::floor(((double)w.lo[s][k] - (double)org[k]) / sc);
                     int hi = (int)std::ceil(((double)w.hi[s][k] - (double)org[k]) / sc);
                     lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
@@ -191,7 +183,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
             // the plane scales 2^e are stored as floats (not as exponent bytes): decoding them on the device -- two ALU operations per axis
             // right behind the load, in front of every slab test -- was measured 10 % slower on the whole bake
             // (times 2^24: the kernel feeds the plane bytes to v_fma_mix_f32 as f16 subnormals q * 2^-24, iris_trace.h node_step)
-            for (int k = 0; k < 3; ++k) p[3 + k] = scale_f[k];
+            for (int k = 0; k < 3; ++k) p[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127 + 24);
             for (int k = 0; k < 6; ++k) std::memcpy(&p[6 + k], q[k], 4);
             for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
         }

@@ -162,9 +162,6 @@ struct RayState {
     f3 o, d;                        // (scratch between fetch and prepare; the traversal itself reads the slab constants and the triangle test's transform)
     float tox, toy, toz, sx, sy, sz;   // triangle test: permuted origin, shear (RayXf)
     uint32_t kz;                    // its axis permutation; the three plane offsets are rebuilt from it at every leaf-phase entry
-#ifdef IRIS_OCTANT_ORDER
-    uint32_t oct;                   // direction octant: bit 0 d.x < 0, bit 1 d.y < 0, bit 2 d.z < 0
-#endif
     float ix, iy, iz, nx, ny, nz;   // 1/d and -o/d
     bool px, py, pz;                // direction signs
     Hit h;
@@ -176,9 +173,6 @@ __device__ __forceinline__ void ray_begin(RayState& r, f3 o, f3 d) {
     r.ix = safe_rcp_dir(d.x); r.iy = safe_rcp_dir(d.y); r.iz = safe_rcp_dir(d.z);
     r.nx = -(o.x * r.ix); r.ny = -(o.y * r.iy); r.nz = -(o.z * r.iz);
     r.px = r.ix >= 0.f; r.py = r.iy >= 0.f; r.pz = r.iz >= 0.f;
-#ifdef IRIS_OCTANT_ORDER
-    r.oct = (r.px ? 0u : 1u) | (r.py ? 0u : 2u) | (r.pz ? 0u : 4u);
-#endif
     { RayXf x; ray_xform(o, d, x); r.tox = x.ox; r.toy = x.oy; r.toz = x.oz; r.sx = x.sx; r.sy = x.sy; r.sz = x.sz; r.kz = x.offz; }
     r.cur = 0;
 }
@@ -234,28 +228,6 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         IRIS_SLAB(k0, x) IRIS_SLAB(k1, y) IRIS_SLAB(k2, z) IRIS_SLAB(k3, w)
 #undef IRIS_SLAB
     }
-#ifdef IRIS_OCTANT_ORDER
-    if (LAYOUT == kLayoutQ8) {
-        // EXPERIMENT (verdict round 2, item 3a): front-to-back order from the ray's octant and the three binary splits the node was collapsed from
-        // (balanced collapse: slots {0,1} | {2,3}); the node carries one table byte per split in the low mantissa bits of its plane scales.
-        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
-        const uint32_t tT = n[0].w, tL = n[1].x, tR = n[1].y;      // (the same registers the slab tests loaded: the compiler merges the loads)
-        const bool fT = (tT >> r.oct) & 1u, fL = (tL >> r.oct) & 1u, fR = (tR >> r.oct) & 1u;
-        const uint32_t a0 = k0 < INFINITY ? r0 : kEmptyRef, a1 = k1 < INFINITY ? r1 : kEmptyRef, a2 = k2 < INFINITY ? r2 : kEmptyRef, a3 = k3 < INFINITY ? r3 : kEmptyRef;
-        const uint32_t p0 = fL ? a1 : a0, p1 = fL ? a0 : a1, p2 = fR ? a3 : a2, p3 = fR ? a2 : a3;
-        const uint32_t c0 = fT ? p2 : p0, c1 = fT ? p3 : p1, c2 = fT ? p0 : p2, c3 = fT ? p1 : p3;
-        const bool v0 = c0 != kEmptyRef, v1 = c1 != kEmptyRef, v2 = c2 != kEmptyRef, v3 = c3 != kEmptyRef;
-        if (v0 || v1 || v2 || v3) {
-            r.cur = v0 ? c0 : (v1 ? c1 : (v2 ? c2 : c3));
-            if (v3 && (v0 || v1 || v2)) st.push(c3);
-            if (v2 && (v0 || v1)) st.push(c2);
-            if (v1 && v0) st.push(c1);
-        } else {
-            r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
-        }
-        return;
-    }
-#endif
     IRIS_CE(k0, r0, k1, r1) IRIS_CE(k2, r2, k3, r3) IRIS_CE(k0, r0, k2, r2) IRIS_CE(k1, r1, k3, r3) IRIS_CE(k1, r1, k2, r2)
     if (k0 < INFINITY) {
         r.cur = r0;
