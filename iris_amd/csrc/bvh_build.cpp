@@ -36,6 +36,7 @@ struct Node2 {
     int32_t left = -1, right = -1;  // internal
     int32_t start = 0, count = 0;   // leaf if count > 0
     int32_t first = 0, ntri = 0;    // the subtree's triangles: order[first, first + ntri)
+    int8_t axis = 0;                // split axis (the left child holds the lower centroids)
 };
 
 struct Builder {
@@ -121,7 +122,7 @@ struct Builder {
             r = build(mid, start + count - mid, depth + 1);
         }
         Node2& nd2 = nodes[me];
-        nd2.left = l; nd2.right = r; nd2.count = 0;
+        nd2.left = l; nd2.right = r; nd2.count = 0; nd2.axis = (int8_t)std::max(best_axis, 0);
         return me;
     }
 };
@@ -186,6 +187,7 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
             for (int k = 0; k < 3; ++k) { w.lo[s][k] = kInf; w.hi[s][k] = -kInf; }
             w.child[s] = -1; w.leaf_start[s] = 0; w.leaf_count[s] = 0;
         }
+        for (int o = 0; o < 8; ++o) for (int s = 0; s < kMaxWidth; ++s) w.order[o][s] = (uint8_t)s;
         return w;
     };
     if (nf <= 0) { out.nodes.push_back(empty_node()); out.depth = 1; return out; }
@@ -301,13 +303,15 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
     out.tri_order.reserve((size_t)nref);
     struct Child { int32_t n2; bool leaf; };
     // the children a subtree contributes when it is given `slots` slots of its parent's wide node
-    auto emit = [&](auto&& self, int32_t n, int slots, std::vector<Child>& outc) -> void {
+    // oct < 0: canonical (left to right); oct in 0..7: at every binary split the child a ray of that octant enters first comes first
+    auto emit = [&](auto&& self, int32_t n, int slots, std::vector<Child>& outc, int oct) -> void {
         const Node2& nd = nodes[(size_t)n];
         const Dp& d = dp[(size_t)n];
         if (nd.count > 0 || slots == 1) { outc.push_back({n, nd.count > 0 || d.leaf != 0}); return; }
-        if (d.k[slots] == 0) { self(self, n, slots - 1, outc); return; }
-        self(self, nd.left, d.k[slots], outc);
-        self(self, nd.right, slots - d.k[slots], outc);
+        if (d.k[slots] == 0) { self(self, n, slots - 1, outc, oct); return; }
+        const bool flip = oct >= 0 && ((oct >> nd.axis) & 1);
+        if (!flip) { self(self, nd.left, d.k[slots], outc, oct); self(self, nd.right, slots - d.k[slots], outc, oct); }
+        else       { self(self, nd.right, slots - d.k[slots], outc, oct); self(self, nd.left, d.k[slots], outc, oct); }
     };
     struct Item { int32_t n2; int32_t wide; int depth; };
     std::vector<Item> queue;
@@ -320,9 +324,20 @@ WideBvh build_wide_bvh(const float* verts, int64_t /*nv*/, const int32_t* faces,
         ch.clear();
         const Node2& r = nodes[(size_t)it.n2];
         if (r.count > 0 || (it.n2 == 0 && dp[0].leaf)) ch.push_back({it.n2, true});      // a root that is itself a leaf: one leaf child
-        else { emit(emit, r.left, dp[(size_t)it.n2].k[W], ch); emit(emit, r.right, W - dp[(size_t)it.n2].k[W], ch); }
+        else { emit(emit, r.left, dp[(size_t)it.n2].k[W], ch, -1); emit(emit, r.right, W - dp[(size_t)it.n2].k[W], ch, -1); }
         WideNode w = empty_node();
         w.n = (int)ch.size();
+        for (int o = 0; o < 8; ++o) {
+            for (int i = 0; i < kMaxWidth; ++i) w.order[o][i] = (uint8_t)i;
+            if (w.n < 2) continue;
+            std::vector<Child> oc;
+            const bool flip = (o >> r.axis) & 1;
+            const int kl = dp[(size_t)it.n2].k[W];
+            if (!flip) { emit(emit, r.left, kl, oc, o); emit(emit, r.right, W - kl, oc, o); }
+            else       { emit(emit, r.right, W - kl, oc, o); emit(emit, r.left, kl, oc, o); }
+            for (size_t j = 0; j < oc.size() && j < (size_t)kMaxWidth; ++j)
+                for (int i = 0; i < w.n; ++i) if (ch[(size_t)i].n2 == oc[j].n2) w.order[o][j] = (uint8_t)i;
+        }
         for (int i = 0; i < w.n; ++i) {          // internal children first get consecutive wide indices
             const Node2& c = nodes[(size_t)ch[(size_t)i].n2];
             for (int k = 0; k < 3; ++k) { w.lo[i][k] = c.b.lo[k] - pad; w.hi[i][k] = c.b.hi[k] + pad; }

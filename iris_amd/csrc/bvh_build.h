@@ -15,6 +15,8 @@ struct WideNode {
     int32_t child[kMaxWidth];        // >=0: index of an internal wide node; -1: leaf
     int32_t leaf_start[kMaxWidth];   // leaf: first triangle in tri_order
     int32_t leaf_count[kMaxWidth];   // leaf: number of triangles
+    uint8_t order[8][kMaxWidth];     // per ray octant (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0): the slots in front-to-back order as the binary splits the
+                                     // node was collapsed from give it (at every split the side the ray enters first; the left child holds the lower centroids)
 };
 
 struct WideBvh {

@@ -126,6 +126,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit);
     if (bvh.tri_order.size() >= (size_t)(1 << 26) - 1) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^26 leaf records");
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
+    if (layout == IRIS_BVH4_Q8 && bvh.nodes.size() >= ((size_t)1 << 23)) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^23 BVH nodes (32-bit byte offsets into the eight octant copies)");
 
     // ---- encode nodes ----
     const size_t nn = bvh.nodes.size();
@@ -139,7 +140,8 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
         return kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
     };
     const int node_floats = layout == IRIS_BVH4_Q8 ? 16 : 32;
-    std::vector<float> nodes(nn * node_floats);
+    const int n_copies = layout == IRIS_BVH4_Q8 ? 8 : 1;       // Q8: one copy of the node table per ray octant (see below)
+    std::vector<float> nodes(nn * node_floats * n_copies);
     for (size_t i = 0; i < nn; ++i) {
         const WideNode& w = bvh.nodes[i];
         float* p = nodes.data() + i * node_floats;
@@ -179,13 +181,33 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
                     q[k][s] = (uint8_t)lo; q[3 + k][s] = (uint8_t)hi;
                 }
             }
-            p[0] = org[0]; p[1] = org[1]; p[2] = org[2];
             // the plane scales 2^e are stored as floats (not as exponent bytes): decoding them on the device -- two ALU operations per axis
             // right behind the load, in front of every slab test -- was measured 10 % slower on the whole bake
             // (times 2^24: the kernel feeds the plane bytes to v_fma_mix_f32 as f16 subnormals q * 2^-24, iris_trace.h node_step)
-            for (int k = 0; k < 3; ++k) p[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127 + 24);
-            for (int k = 0; k < 6; ++k) std::memcpy(&p[6 + k], q[k], 4);
-            for (int s = 0; s < 4; ++s) { uint32_t ref = child_ref(w, s); std::memcpy(&p[12 + s], &ref, 4); }
+            //
+            // ONE COPY PER RAY OCTANT (round 3): copy o (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0) holds the children in the front-to-back order
+            // the node's binary splits give a ray of that octant (WideNode::order), and per axis the plane the ray meets FIRST in the "near" bytes:
+            //   {origin.xyz, scale.x} {scale.y, scale.z, near_x[4], near_y[4]} {near_z[4], far_x[4], far_y[4], far_z[4]} {ref[4]}
+            // so that a node visit neither selects planes by the ray's signs (6 selects) nor sorts the children (5 compare-exchanges): 8 x 64 B per
+            // node -- 105 MB for the bench scene next to 288 GB -- against ~30 vector instructions per visit.  Child references are node indices
+            // (the same in every copy); a ray adds its copy's base offset (SceneDev::oct_stride).
+            for (int o = 0; o < 8; ++o) {
+                float* po = nodes.data() + ((size_t)o * nn + i) * 16;
+                po[0] = org[0]; po[1] = org[1]; po[2] = org[2];
+                for (int k = 0; k < 3; ++k) po[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127 + 24);
+                uint8_t qo[6][4];
+                for (int j = 0; j < 4; ++j) {
+                    const int sl = j < w.n ? (int)w.order[o][j] : j;          // (unused slots: the canonical inverted box (lo 255, hi 0) goes through the same swap, so it is empty for either sign)
+                    for (int k = 0; k < 3; ++k) {
+                        const bool neg = (o >> k) & 1;
+                        qo[k][j] = neg ? q[3 + k][sl] : q[k][sl];             // near
+                        qo[3 + k][j] = neg ? q[k][sl] : q[3 + k][sl];         // far
+                    }
+                    const uint32_t ref = child_ref(w, sl);
+                    std::memcpy(&po[12 + j], &ref, 4);
+                }
+                for (int k = 0; k < 6; ++k) std::memcpy(&po[6 + k], qo[k], 4);
+            }
         }
     }
     // ---- encode leaf triangles (64 B, one per 64-B line), component-major so that the watertight test's axis permutation is an address
@@ -213,6 +235,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     s->dev.n_nodes = (int)nn;
     s->dev.n_tris = (int)nt;
     s->dev.layout = layout == IRIS_BVH4_Q8 ? kLayoutQ8 : kLayoutF32;
+    s->dev.oct_stride = layout == IRIS_BVH4_Q8 ? (uint32_t)(nn * 64) : 0u;
     s->dev.phase_min = kPhaseMin;
     if (g_opt_phase_min >= 0) s->dev.phase_min = (int)g_opt_phase_min;  // iris_debug_set("phase_min") (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;

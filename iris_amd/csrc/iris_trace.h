@@ -19,6 +19,7 @@ struct SceneDev {
     int n_tris;
     int phase_min;  // wave-level phase scheduling threshold (see trace_bvh4)
     int layout;     // kLayoutF32 | kLayoutQ8
+    uint32_t oct_stride;   // Q8: bytes between the node-table copies of two ray octants (n_nodes * 64)
 };
 
 struct Hit {
@@ -162,17 +163,19 @@ struct RayState {
     f3 o, d;                        // (scratch between fetch and prepare; the traversal itself reads the slab constants and the triangle test's transform)
     float tox, toy, toz, sx, sy, sz;   // triangle test: permuted origin, shear (RayXf)
     uint32_t kz;                    // its axis permutation; the three plane offsets are rebuilt from it at every leaf-phase entry
+    uint32_t oct_base;              // Q8 nodes: byte offset of the node-table copy of this ray's octant
     float ix, iy, iz, nx, ny, nz;   // 1/d and -o/d
     bool px, py, pz;                // direction signs
     Hit h;
     uint32_t cur;                   // node / leaf reference (a leaf reference is consumed in place: start + 1, count - 1 per test), kEmptyRef = no work
 };
-__device__ __forceinline__ void ray_begin(RayState& r, f3 o, f3 d) {
+__device__ __forceinline__ void ray_begin(const SceneDev& sc, RayState& r, f3 o, f3 d) {
     r.o = o; r.d = d;
     r.h.t = INFINITY; r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1; r.h.id = (int)0x80000000;   // (INT_MIN: see tri_test)
     r.ix = safe_rcp_dir(d.x); r.iy = safe_rcp_dir(d.y); r.iz = safe_rcp_dir(d.z);
     r.nx = -(o.x * r.ix); r.ny = -(o.y * r.iy); r.nz = -(o.z * r.iz);
     r.px = r.ix >= 0.f; r.py = r.iy >= 0.f; r.pz = r.iz >= 0.f;
+    r.oct_base = ((r.px ? 0u : 1u) | (r.py ? 0u : 2u) | (r.pz ? 0u : 4u)) * sc.oct_stride;
     { RayXf x; ray_xform(o, d, x); r.tox = x.ox; r.toy = x.oy; r.toz = x.oz; r.sx = x.sx; r.sy = x.sy; r.sz = x.sz; r.kz = x.offz; }
     r.cur = 0;
 }
@@ -185,33 +188,52 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
     const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
     const bool px = r.px, py = r.py, pz = r.pz;
     if (LAYOUT == kLayoutQ8) {
-        // 32-bit byte offset from the (scalar) table base: one shift instead of a 64-bit shift + add per visit (the node table is < 4 GB)
-        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(r.cur << 6));
+        // The node table exists once per ray octant (iris_hip.hip): the copy a ray reads holds the children in ITS front-to-back order (the order of
+        // the binary splits the node was collapsed from) and, per axis, the plane it meets first in the "near" bytes -- so a visit selects no planes
+        // by the ray's signs and sorts nothing.  32-bit byte offset from the (scalar) table base: one shift-add per visit.
+        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)((r.cur << 6) + r.oct_base));
         const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
         // per-axis: t(q) = q * 2^e * idir + (origin * idir - o * idir); the node stores 2^(e+24) as a float (see below)
         const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
         const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
-        const uint32_t nxq = px ? q1.z : q2.y, fxq = px ? q2.y : q1.z;
-        const uint32_t nyq = py ? q1.w : q2.z, fyq = py ? q2.z : q1.w;
-        const uint32_t nzq = pz ? q2.x : q2.w, fzq = pz ? q2.w : q2.x;
+        const uint32_t nxq = q1.z, nyq = q1.w, nzq = q2.x, fxq = q2.y, fyq = q2.z, fzq = q2.w;
         // A plane byte q, zero-extended to 16 bits, IS the f16 subnormal q * 2^-24; v_perm_b32 puts the near and the far byte of one
         // child into the two halves of a register and v_fma_mix_f32 reads an f16 operand directly: 1 + 2 instructions per axis and child
         // instead of 2 conversions + 2 FMAs.  The node stores scale * 2^24, so q*2^-24 * (scale*2^24*idir) + b is the same real number,
-        // rounded once by the FMA: the same t as before, bit for bit.
+        // rounded once by the FMA.
         typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
 #define IRIS_PLANES(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
-#define IRIS_SLABQ(K, C)                                                                                                          \
+#define IRIS_SLABQ(D, C)                                                                                                          \
     {                                                                                                                             \
         const iris_h2 hx = IRIS_PLANES(nxq, fxq, C), hy = IRIS_PLANES(nyq, fyq, C), hz = IRIS_PLANES(nzq, fzq, C);                 \
         float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
         float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
-        K = IRIS_HITKEY(tn, tf);                                                                                                  \
-    }
-        IRIS_SLABQ(k0, 0) IRIS_SLABQ(k1, 1) IRIS_SLABQ(k2, 2) IRIS_SLABQ(k3, 3)
+        D = tf - tn;                     /* sign clear: the child is hit (tn <= tf).  tn = tf gives +0; a NaN (inf - inf: tn = tf = inf) with a clear sign  */ \
+    }                                    /* would only cost a wasted visit                                                                                */
+        float d0, d1, d2, d3;
+        IRIS_SLABQ(d0, 0) IRIS_SLABQ(d1, 1) IRIS_SLABQ(d2, 2) IRIS_SLABQ(d3, 3)
 #undef IRIS_SLABQ
 #undef IRIS_PLANES
-        // (the four 16-B loads are issued together; sinking the child-reference load behind the hit test is neutral today)
+        // Slots are in visiting order: the first child hit is next, the others wait on the stack, the farthest at the bottom.  The conditions are
+        // taken from the SIGN BITS of the interval lengths with integer and / or (2-cycle dual-issue instructions; boolean algebra on compare results is
+        // what hipcc turns into 0 / 1 registers, and fminf / fmaxf bring a canonicalising v_max x, x per operand): "child j is hit" = sign clear.
+        const int32_t b0 = __float_as_int(d0), b1 = __float_as_int(d1), b2 = __float_as_int(d2), b3 = __float_as_int(d3);
+        const int32_t n01 = b0 & b1, n012 = n01 & b2;           // sign set: none of these children is hit
+        // (the references are needed whichever child is hit: this keeps their load with the plane loads instead of behind the hit test, where hipcc
+        //  sinks it otherwise -- a second dependent round trip per visit, measured -8 %)
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        if ((n012 & b3) >= 0) {
+            uint32_t c = b2 >= 0 ? r2 : r3;                     // (selects, written innermost first: as a nested ?: hipcc makes this three branches)
+            c = b1 >= 0 ? r1 : c;
+            r.cur = b0 >= 0 ? r0 : c;
+            if ((b3 | n012) >= 0) st.push(r3);                  // hit, and a nearer child is hit too
+            if ((b2 | n01) >= 0) st.push(r2);
+            if ((b1 | b0) >= 0) st.push(r1);
+        } else {
+            r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+        }
+        return;
     } else {
         const float4* n = sc.nodes + (int64_t)r.cur * 8;
         const float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5];
@@ -258,7 +280,7 @@ __device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, const
 template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
     RayState r;
-    ray_begin(r, o, d);
+    ray_begin(sc, r, o, d);
     Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
@@ -312,7 +334,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                                              Retire retire) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
-    ray_begin(r, r.o, r.d);
+    ray_begin(sc, r, r.o, r.d);
     r.cur = kEmptyRef;
     Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
@@ -325,7 +347,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
         if (pend) {
             if ((pend >> (threadIdx.x & 63)) & 1ull) {
                 prepare(r.o, r.d);
-                ray_begin(r, r.o, r.d);
+                ray_begin(sc, r, r.o, r.d);
                 st.sp = 0;
                 if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
             }
