@@ -35,6 +35,17 @@ static void check_tree(const char* name, const std::vector<float>& v, const std:
     for (size_t i = 0; i < b.nodes.size(); ++i) {
         const WideNode& w = b.nodes[i];
         CHECK(w.n >= 0 && w.n <= width, "%s: node %zu has %d children", name, i, w.n);
+        // per ray octant the slots in front-to-back order: a permutation of the children, octant 0 = the canonical (left-to-right) order, and two
+        // octants that differ in every axis visit in exactly opposite order
+        for (int o = 0; o < 8; ++o) {
+            int mask = 0;
+            for (int j = 0; j < w.n; ++j) { CHECK(w.order[o][j] < w.n, "%s: node %zu octant %d order entry %d", name, i, o, (int)w.order[o][j]); mask |= 1 << w.order[o][j]; }
+            CHECK(mask == (1 << w.n) - 1, "%s: node %zu octant %d: order is not a permutation", name, i, o);
+            for (int j = 0; j < w.n; ++j) {
+                if (o == 0) CHECK(w.order[0][j] == j, "%s: node %zu: octant 0 is not the canonical order", name, i);
+                CHECK(w.order[o][j] == w.order[7 - o][w.n - 1 - j], "%s: node %zu: octants %d and %d are not mirror images", name, i, o, 7 - o);
+            }
+        }
         int32_t prev_child = -1;
         for (int s = 0; s < w.n; ++s) {
             if (w.child[s] >= 0) {
