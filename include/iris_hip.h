@@ -49,7 +49,8 @@ typedef struct {
     int64_t n_vertices, n_triangles;
     int32_t layout;        /* IRIS_BVH4_F32 | IRIS_BVH4_Q8 */
     int32_t n_nodes;       /* wide nodes */
-    int32_t node_bytes;    /* bytes per node as stored in HBM */
+    int32_t node_bytes;    /* bytes per node record (64: quantised planes); the default layout keeps EIGHT records per node, one per ray octant
+                              (children in that octant's front-to-back order, planes pre-swapped near / far): table = 8 * n_nodes * node_bytes */
     int32_t tri_bytes;     /* stride of a leaf-triangle record (64: component-major (p0.x,p1.x,p2.x,id) (y...) (z...), csrc/iris_trace.h) */
     int32_t depth;         /* wide-tree depth */
     int32_t n_leaf_records;/* leaf-triangle records: n_triangles + the extra references of split long triangles */
