@@ -18,10 +18,11 @@ __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     }
     int ix = min(15, max(0, (int)((px * 0.5f + 0.5f) * 16.f)));
     int iy = min(15, max(0, (int)((py * 0.5f + 0.5f) * 16.f)));
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m |= (((uint32_t)ix >> k) & 1u) << (2 * k) | (((uint32_t)iy >> k) & 1u) << (2 * k + 1);
-    return m;
+    // Morton interleave of two 4-bit numbers: spread each over the even bits (abcd -> 0a0b0c0d), then or
+    uint32_t x = (uint32_t)ix, y = (uint32_t)iy;
+    x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
+    y = (y | (y << 2)) & 0x33u; y = (y | (y << 1)) & 0x55u;
+    return x | (y << 1);
 }
 
 // Diagnostic build (-DIRIS_PHASE_TIMING, tools/diag_phases.py): shader cycles every workgroup spends in the phases of a tile, summed over
