@@ -29,7 +29,10 @@ struct BakeArgs {
     int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
 };
 
-constexpr int kTileRays = 5120;   // capacity of the LDS ray list (10 KiB) = largest spp of the tile kernels; the host aims at tiles of this size
+#ifndef IRIS_TILE_RAYS
+#define IRIS_TILE_RAYS 5120
+#endif
+constexpr int kTileRays = IRIS_TILE_RAYS;   // capacity of the LDS ray list (10 KiB) = largest spp of the tile kernels; the host aims at tiles of this size
 
 // lanes-per-pixel / pixels-per-wave geometry of the per-pixel reduction (shared by all bake kernels so that the sums match)
 __device__ __forceinline__ void reduce_geometry(int spp, int& lpp, int& ppw, int& rounds) {

@@ -833,7 +833,10 @@ static int tile_pixels(int spp) {
     const int target = g_opt_tile_target_rays > 0 ? (int)std::min<long long>(kTileRays, std::max<long long>(64, g_opt_tile_target_rays)) : kTileTarget;
     return std::max(1, std::min(kTileRays, std::max(target, spp)) / spp);
 }
-static int bake_grid_blocks() { return num_cus() * IRIS_TILE_WAVES; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
+#ifndef IRIS_TILE_GRID
+#define IRIS_TILE_GRID IRIS_TILE_WAVES
+#endif
+static int bake_grid_blocks() { return num_cus() * IRIS_TILE_GRID; }  // resident 256-thread workgroups per CU (VGPR- and LDS-bound)
 static int view_grid_blocks() { return bake_grid_blocks(); }
 static uint64_t stack_ovf_bytes() {
     return (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kStackCapacity - IRIS_TILE_STACK) * kBlock * sizeof(uint32_t);
