@@ -934,6 +934,7 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     v.n_lobes = n_lobes;
     const int blocks = view_grid_blocks();
     long long t = 0;
+    int tile_px_min = kTileRays;
     for (int l = 0; l < n_lobes; ++l) {
         if (spp[l] < 1 || spp[l] > kTileRays) return fail(IRIS_ERR_ARG, "iris_bake_view: spp must be in [1, iris_bake_tile_max_spp()]");
         if (!out0[l] || (roughness[l] >= 0.f && !out1[l])) return fail(IRIS_ERR_ARG, "iris_bake_view: null output");
@@ -942,11 +943,16 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
         if (even < tile_px) tile_px = (int)std::max<int64_t>(even, std::min(tile_px, 16));
         if (tile_px < 1) tile_px = 1;
         v.lobe[l].rough = roughness[l]; v.lobe[l].spp = spp[l]; v.lobe[l].stream_id = stream_ids[l]; v.lobe[l].spec = roughness[l] >= 0.f ? 1 : 0;
-        v.lobe[l].tile_px = tile_px; v.lobe[l].tile_begin = t; v.lobe[l].out0 = out0[l]; v.lobe[l].out1 = out1[l];
+        v.lobe[l].tile_px = tile_px; v.lobe[l].out0 = out0[l]; v.lobe[l].out1 = out1[l];
+        tile_px_min = std::min(tile_px_min, tile_px);
         t += (P + tile_px - 1) / tile_px;
     }
+    // the queue's virtual numbering (ViewArgs): spans of kTileChunk tiles of the lobe with the smallest tiles
+    v.span_px = kTileChunk * tile_px_min;
+    for (int l = 0; l < n_lobes; ++l) v.lobe[l].tiles_per_span = (v.span_px + v.lobe[l].tile_px - 1) / v.lobe[l].tile_px;
+    const long long n_spans = (P + v.span_px - 1) / v.span_px;
     hipStream_t st = (hipStream_t)stream;
-    v.n_tiles = t;
+    v.n_tiles = ((n_spans + 7) / 8) * 8 * n_lobes * kTileChunk;
     HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
     const int grid = (int)std::min<long long>(blocks, t);
     if (v.base.sc.layout == kLayoutQ8) hipLaunchKernelGGL(bake_view_kernel<kLayoutQ8>, dim3(grid), dim3(kBlock), 0, st, v);
