@@ -624,6 +624,18 @@ def test_view_kernel_equals_per_lobe_launches(dev, room_setup):
     for k in range(6):
         a, b = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, levels[k], spps[k + 1], seed=9, stream_id=1 + k, pix_id=pix)
         assert torch.equal(res[k + 1][0], a) and torch.equal(res[k + 1][1], b), k
+    # enough pixels that the lobes keep DIFFERENT tile sizes (16 / 64 / 32 pixels) over many spans of the span-major tile queue (ViewArgs, iris_bake.h):
+    # every (lobe, pixel) must be baked exactly once, ragged last span included
+    n0 = s["pos"].shape[0]
+    rep = (70_001 + n0 - 1) // n0
+    P = 70_001
+    big = [T(np.tile(s[k], (rep, 1))[:P].copy(), dev) for k in ("pos", "nrm", "wo")]
+    pix = T(np.arange(P, dtype=np.int32), dev)
+    res = bs.bake_lobes(s["sc"], s["em"], *big, rough, spps, seed=5, pix_id=pix)
+    assert torch.equal(res[0], bs.bake_diffuse(s["sc"], s["em"], big[0], big[1], 256, seed=5, stream_id=0, pix_id=pix))
+    for k in (0, 3):
+        a, b = bs.bake_specular(s["sc"], s["em"], *big, levels[k], spps[k + 1], seed=5, stream_id=1 + k, pix_id=pix)
+        assert torch.equal(res[k + 1][0], a) and torch.equal(res[k + 1][1], b), k
     one = bs.bake_lobes(s["sc"], s["em"], pos[:1], nrm[:1], wo[:1], [0.5], [16], seed=1, stream_ids=[4])
     a, b = bs.bake_specular(s["sc"], s["em"], pos[:1], nrm[:1], wo[:1], 0.5, 16, seed=1, stream_id=4)
     assert torch.equal(one[0][0], a) and torch.equal(one[0][1], b)
