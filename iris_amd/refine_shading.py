@@ -22,7 +22,8 @@ from .utils.path_tracing import path_tracing_det_diff, path_tracing_det_spec, ra
 SPP_DIFFUSE = 128          # refine_shading.py:103
 SPP_SPECULAR = 64          # refine_shading.py:137
 INDIR_DEPTH = 5            # refine_shading.py:104
-BATCH_RAYS = 10240 * 128   # rays per integrator call: batch_size = 10240*128//spp pixels (refine_shading.py:107, :139)
+REFERENCE_BATCH_RAYS = 10240 * 128   # the reference's rays per integrator call: batch_size = 10240*128//spp pixels (refine_shading.py:107, :139), sized for its GPU memory
+BATCH_RAYS = 16 * REFERENCE_BATCH_RAYS   # default here: 21 M paths per call (a few GB of path state next to 288 GB) -- 2 x the paths per second of the reference's batches
 
 
 @torch.no_grad()
@@ -115,6 +116,7 @@ def main(argv=None):
     parser.add_argument("--spp_diffuse", type=int, default=SPP_DIFFUSE)
     parser.add_argument("--spp_specular", type=int, default=SPP_SPECULAR)
     parser.add_argument("--indir_depth", type=int, default=INDIR_DEPTH)
+    parser.add_argument("--batch_rays", type=int, default=BATCH_RAYS, help="paths per integrator call (the reference: 10240*128)")
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--compression", type=str, default="zip", choices=["none", "zips", "zip"])
     parser.add_argument("--overwrite", action="store_true", help="(accepted for symmetry with bake_shading; refining always overwrites, as the reference does)")
@@ -178,7 +180,7 @@ def main(argv=None):
             os.remove(marker)
         torch.manual_seed(args.seed * 1000003 + im_id); torch.cuda.manual_seed(args.seed * 1000003 + im_id)     # the integrators draw with torch.rand
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
-        out = refine_view(scene, emitter, material_net, xs, ds, args.spp_diffuse, args.spp_specular, args.indir_depth, denoiser=denoiser)
+        out = refine_view(scene, emitter, material_net, xs, ds, args.spp_diffuse, args.spp_specular, args.indir_depth, batch_rays=args.batch_rays, denoiser=denoiser)
         writer.submit(files, torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3))
         done.append(marker)
     writer.close()                                             # every file is on disk from here on
