@@ -50,7 +50,13 @@ template <bool SPEC>
 __device__ __forceinline__ void sample_lobe(const BakeArgs& a, int64_t p, int s, f3 n, f3 w, f3 t, f3 b, uint64_t base, f3& wi, float& g0, float& g1) {
     float u0, u1;
     if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
-    else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+    else {
+        // (the ten round keys are wave-uniform: left to itself hipcc hoists them out of the sampling loop into 20 scalar registers it does not have and
+        //  reloads them from vector-register lanes every iteration; behind this barrier they are re-derived by scalar adds, which cost no vector issue)
+        uint32_t s_lo = (uint32_t)a.seed, s_hi = (uint32_t)(a.seed >> 32);
+        asm volatile("" : "+s"(s_lo), "+s"(s_hi));
+        philox_u2(((uint64_t)s_hi << 32) | s_lo, base + (uint64_t)s, a.stream_id, u0, u1);
+    }
     g0 = 1.f; g1 = 0.f;
     if (SPEC) {
         wi = specular_sampler(u0, u1, a.rough, w, n, t, b);

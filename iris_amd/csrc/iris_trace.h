@@ -319,11 +319,12 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 // Persistent-lane traversal ("dynamic fetch"): a lane whose ray is finished does not wait for the slowest ray of its wave;
 // once kRefillMin lanes are idle they retire their hits and fetch new rays together.  Same node / leaf steps and phase
 // scheduling as trace_bvh4, so per-ray results are identical; only which rays share a wave changes.
-//   fetch(o, d)  -> bool : called by the idle lanes together: claim a ray and ISSUE the loads of its raw data into o / d without
-//                          using them (they complete behind one step of the other lanes); false = no ray left
-//   prepare(o, d)        : one round later, turn the raw data into origin / direction (first use of the loaded values)
+//   fetch(o, d)  -> bool : called by the idle lanes together: claim a ray and load its raw data into o / d; false = no ray left
+//   prepare(o, d)        : turn the raw data into origin / direction
 //   retire(h)            : called by a lane whose ray is complete, before it fetches again / at the end
 // Measured on the 7-lobe bake: threshold 16: -1 %, 32: +4 %, 48: +7 %, 56: +4 %, 64 (= no refill): -4 %.
+// A fetched ray is activated at once.  (Rounds 1-3 issued the loads in one round and activated the ray in the next, behind one node / leaf step of the
+// other lanes: the six registers the raw data waited in and the extra loop exits cost more than the hidden latency was worth -- +1.2 % without.)
 // -------------------------------------------------------------------------------------------------------
 #ifndef IRIS_REFILL_MIN
 #define IRIS_REFILL_MIN 48
@@ -339,21 +340,10 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
     Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
-    unsigned long long pend = 0;   // wave-uniform: lanes whose next ray has been requested but not activated
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
-        // ---------------- activate the lanes whose ray data was requested in the previous round
-        if (pend) {
-            if ((pend >> (threadIdx.x & 63)) & 1ull) {
-                prepare(r.o, r.d);
-                ray_begin(sc, r, r.o, r.d);
-                st.sp = 0;
-                if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
-            }
-            pend = 0;
-        }
-        // ---------------- retire finished rays + request new ones
+        // ---------------- retire finished rays, fetch and start new ones
         const bool idle = r.cur == kEmptyRef;
         const int n_idle = __popcll(__ballot(idle));
         if (more && (n_idle >= kRefillMin || n_idle == __popcll(__ballot(1)))) {
@@ -362,11 +352,16 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 if (live) retire(r.h);
                 live = got = fetch(r.o, r.d);
             }
-            pend = __ballot(got);
-            if (pend == 0) more = false;
+            if (__ballot(got) == 0) more = false;
+            if (got) {
+                prepare(r.o, r.d);
+                ray_begin(sc, r, r.o, r.d);
+                st.sp = 0;
+                if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
+            }
         }
         if (__ballot(r.cur != kEmptyRef) == 0) {
-            if (pend == 0 && !more) break;
+            if (!more) break;
             continue;
         }
         // ---------------- node phase
@@ -381,7 +376,6 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 node_step<LAYOUT>(sc, r, st);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }
-            if (pend) break;   // requested rays have had one step to arrive: go activate them
         }
         // ---------------- leaf phase
         const RayXf xf = leaf_phase_xform(r);
@@ -395,7 +389,6 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
                 leaf_step(sc, r, xf, st);
             }
-            if (pend) break;
         }
     }
     if (live) retire(r.h);
