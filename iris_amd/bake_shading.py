@@ -160,6 +160,26 @@ class LobeStreams:
             self.main.wait_stream(st)
 
 
+_BLOCK_ORDER = {}     # (rows, id(pixel_ids), image_width, block, device) -> (pixel_ids kept alive, its version, permutation): a view sequence reuses one entry
+
+
+def _block_order(n, pixel_ids, image_width, block, device):
+    """Permutation of the rows 0..n-1 (image pixel pixel_ids[row], or row itself) that lists them block x block image tile by tile, row-major inside a
+    tile.  Depends only on the camera raster (and the rank's stripes), so it is computed once and kept."""
+    key = (n, None if pixel_ids is None else id(pixel_ids), image_width, block, str(device))
+    hit = _BLOCK_ORDER.get(key)
+    if hit is not None and (pixel_ids is None or (hit[0] is pixel_ids and hit[1] == pixel_ids._version)):
+        return hit[2]
+    pix = torch.arange(n, device=device) if pixel_ids is None else pixel_ids.to(device=device, dtype=torch.int64)
+    y, x = pix // image_width, pix % image_width
+    nbx = (image_width + block - 1) // block
+    perm = torch.argsort(((y // block) * nbx + x // block) * (block * block) + (y % block) * block + x % block)
+    if len(_BLOCK_ORDER) >= 8:
+        _BLOCK_ORDER.pop(next(iter(_BLOCK_ORDER)))
+    _BLOCK_ORDER[key] = (pixel_ids, None if pixel_ids is None else pixel_ids._version, perm)
+    return perm
+
+
 def primary_hits(scene, xs, ds, pixel_ids=None, image_width=None, block=8):
     """bake_shading.py:98-101 / :154-157: primary closest hit + compaction to the valid pixels.
     Returns dict(position, normal, wo, pix_id (int32 image-space pixel index), sel, n_pixels).
@@ -168,14 +188,13 @@ def primary_hits(scene, xs, ds, pixel_ids=None, image_width=None, block=8):
     order of the pixel list changes neither the results (sample streams are keyed by pix_id) nor the caller's layout
     (`sel` scatters the rows back)."""
     positions, normals, _, _, valid = ray_intersect(scene, xs, ds)
-    sel = torch.nonzero(valid, as_tuple=False).reshape(-1)
+    if image_width is not None:
+        # rows in block order, then the valid ones among them: the same list as sorting the valid rows by block key, without a sort per view
+        perm = _block_order(xs.shape[0], pixel_ids, image_width, block, xs.device)
+        sel = perm[valid[perm]]
+    else:
+        sel = torch.nonzero(valid, as_tuple=False).reshape(-1)
     pix = sel if pixel_ids is None else pixel_ids[sel]
-    if image_width is not None and sel.numel() > 0:
-        y, x = pix // image_width, pix % image_width
-        nbx = (image_width + block - 1) // block
-        key = ((y // block) * nbx + x // block) * (block * block) + (y % block) * block + x % block
-        order = torch.argsort(key)
-        sel, pix = sel[order], pix[order]
     return {"position": positions[sel], "normal": normals[sel], "wo": -ds.reshape(-1, 3)[sel],
             "pix_id": pix.to(torch.int32), "sel": sel, "n_pixels": xs.shape[0]}
 
