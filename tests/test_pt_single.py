@@ -149,6 +149,44 @@ def test_hip_path_tracing_single_forward_backward(tmp_path, oracle_mod):
     assert int((g2.abs().sum(-1) > 0).sum()) <= int(g["is_emitter"].sum())
 
 
+@pytest.mark.gpu
+def test_training_step_replayed_as_hip_graph(tmp_path):
+    """forward + backward of the un-compacted mode captured once as a HIP graph (torch.cuda.CUDAGraph) and replayed: every launch of the path
+    is stream-ordered and allocates nothing outside torch's pool, so the replay gives what the eager step gives (the scatter-add of the
+    backward pass: up to summation order)."""
+    from iris_amd.utils.path_tracing import path_tracing_single
+    from tools.bench_pt_single import GpuStub
+    dev = torch.device("cuda:0")
+    g, p, sc, em = _gpu_setup(tmp_path, dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B, spp = p["rays_o"].shape[0], int(p["spp"])
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    unif = [torch.rand(2, B, spp, 1, generator=gen).to(dev)] + [torch.rand(*((B * spp,) + t), generator=gen).to(dev) for t in ((), (2,), (), (2,))]
+    ro, rd, dxu, dyv, w = T(p["rays_o"]), T(p["rays_d"]), T(p["dx_du"]), T(p["dy_dv"]), T(p["grad_weight"])
+    mat = GpuStub()
+
+    def step():
+        L = path_tracing_single(sc, em, mat, ro, rd, dxu, dyv, spp, uniforms=unif, compact=False)
+        (L * w).sum().backward()
+        return L
+    em.radiance.grad = torch.zeros_like(em.radiance)
+    L_eager = step().detach().clone(); g_eager = em.radiance.grad.clone()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # (torch's recipe: warm up on a side stream before capturing)
+        em.radiance.grad.zero_(); step()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        em.radiance.grad.zero_()
+        L_static = step()
+    for _ in range(2):
+        L_static.detach().fill_(-1.0); em.radiance.grad.fill_(-1.0)
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(L_static.detach(), L_eager)
+        assert rel_l2(em.radiance.grad.cpu().numpy(), g_eager.cpu().numpy()) <= 1e-6
+    em.radiance.grad = None
+
+
 # --------------------------------------------------------------------------------------------------------- path_tracing (render.py's integrator)
 def _full(oracle_mod):
     g, p = golden("bake_box.npz"), golden("pt_full.npz")

@@ -11,12 +11,14 @@ import numpy as np, torch
 class GpuStub(torch.nn.Module):
     """closed-form stand-in for NGPBRDF, evaluated on the GPU"""
     def forward(self, x):
-        k = torch.tensor([1.3, 2.1, 0.7], device=x.device); ph = torch.tensor([0.1, 0.5, 0.9], device=x.device)
+        if getattr(self, "_k", None) is None or self._k.device != x.device:        # (constants uploaded once: a host-to-device copy cannot be captured in a graph)
+            self._k = torch.tensor([1.3, 2.1, 0.7], device=x.device); self._ph = torch.tensor([0.1, 0.5, 0.9], device=x.device)
+        k, ph = self._k, self._ph
         return {"albedo": 0.5 + 0.4 * torch.sin(x * k + ph), "roughness": 0.35 + 0.3 * torch.sin(x[:, :1] * 1.7 + x[:, 1:2] * 0.9),
                 "metallic": 0.5 + 0.5 * torch.sin(x[:, 2:3] * 2.3)}
 
 
-def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp=32, calls=4):
+def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp=32, calls=4, graph=False):
     """-> dict: Mpaths/s of `steps` training steps (each `calls` forward calls + one backward) on an existing bench workload"""
     from iris_amd.model.emitter import SLFEmitterLearn
     from iris_amd.utils.path_tracing import path_tracing_single
@@ -49,6 +51,32 @@ def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp
         return loss
     for _ in range(warmup):
         step()
+    if graph:
+        # the whole training step -- `calls` forward passes, the loss, the backward scatter -- captured once as a HIP graph and replayed: every launch of
+        # the path (ctypes or torch) is stream-ordered and allocates only through torch's graph pool; torch.rand draws advance with every replay
+        em.radiance.grad = torch.zeros_like(em.radiance)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                em.radiance.grad.zero_()
+                loss = 0
+                for _ in range(calls):
+                    L = path_tracing_single(scene, em, mat, o, d, dx, dy, spp)
+                    loss = loss + ((L - target) ** 2).mean()
+                loss.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            em.radiance.grad.zero_()
+            loss = 0
+            for _ in range(calls):
+                L = path_tracing_single(scene, em, mat, o, d, dx, dy, spp)
+                loss = loss + ((L - target) ** 2).mean()
+            loss.backward()
+        step = g_.replay
+        step(); torch.cuda.synchronize()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -56,7 +84,7 @@ def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp
     paths = steps * calls * rays * spp
     return {"metric": "path_tracing_single fwd+bwd (BASELINE configs[4]: train_emitter.py:181-189)", "value": round(paths / dt / 1e6, 2), "unit": "Mpaths/s",
             "ms_per_step": round(dt / steps * 1e3, 2),
-            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "triangles": int(room["faces"].shape[0]), "material": "closed-form stub (NGPBRDF is third party)"},
+            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "hip_graph": bool(graph), "triangles": int(room["faces"].shape[0]), "material": "closed-form stub (NGPBRDF is third party)"},
             "grad_nonzero_rows": int((em.radiance.grad.abs().sum(-1) > 0).sum())}
 
 
@@ -65,12 +93,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rays", type=int, default=8192); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--calls", type=int, default=4)
     ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--graph", action="store_true", help="capture the training step in a HIP graph (torch.cuda.CUDAGraph) and replay it")
     args = ap.parse_args()
     import bench
     dev = torch.device("cuda:0")
     ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
     room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
-    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls)))
+    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph)))
 
 
 if __name__ == "__main__":
