@@ -10,12 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 
 
-class GpuStub(torch.nn.Module):
-    """closed-form stand-in for NGPBRDF (third party), evaluated on the GPU"""
-    def forward(self, x):
-        k = torch.tensor([1.3, 2.1, 0.7], device=x.device); ph = torch.tensor([0.1, 0.5, 0.9], device=x.device)
-        return {"albedo": 0.5 + 0.4 * torch.sin(x * k + ph), "roughness": 0.35 + 0.3 * torch.sin(x[:, :1] * 1.7 + x[:, 1:2] * 0.9),
-                "metallic": 0.5 + 0.5 * torch.sin(x[:, 2:3] * 2.3)}
+from tools.bench_pt_single import GpuStub          # closed-form stand-in for NGPBRDF, constants uploaded once
 
 
 def main():
