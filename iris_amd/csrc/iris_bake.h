@@ -4,7 +4,7 @@
 //   bake_kernel       pixel-per-wave: one pixel per wave, lanes = samples (maximally incoherent rays inside a wave).  The simple
 //                     reference implementation of the fixed reduction order; used for spp > 5120 and as the A/B baseline.
 //   bake_tile_kernel  one lobe per launch: a persistent workgroup owns a TILE of consecutive pixels (~5120 rays), samples and bins
-//                     the tile's rays by direction (octahedral 16x16 map, Morton order) with an LDS counting sort, traces them in
+//                     the tile's rays by direction (octant-major bins, iris_tile.h) with an LDS counting sort, traces them in
 //                     sorted order with persistent lanes (trace_stream), then shades and reduces each pixel's samples in the SAME
 //                     fixed order as bake_kernel -> bit-identical outputs (tile_body below).
 //   bake_view_kernel  all lobes of a view behind one persistent launch and one tile queue (same tile_body, same bits).

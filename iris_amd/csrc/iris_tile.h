@@ -21,22 +21,22 @@ namespace iris {
 #define IRIS_PRIO_D 0
 #endif
 
-// Direction bin: octahedral map of the unit vector to [0,1)^2, 16x16 cells, Morton-interleaved (adjacent codes = adjacent cones)
+// Direction bin, octant-major: key = octant (3 bits: the signs of d) | cell inside the octant (5 bits).  The BVH node table exists once per ray octant
+// (iris_trace.h), so rays of one octant share node lines and visit children in the same order, and rays of different octants share nothing: a wave
+// whose 64 consecutive rays of the sorted list come from one octant touches fewer lines per load.  Inside the octant the L1-normalised |d| lies in a
+// triangle (a + b <= 1), mapped to the unit square by (a, b / (1 - a)) and cut into 8 x 4 cells, columns walked alternately up and down.
+// Measured against the 16 x 16 Morton-ordered octahedral map of rounds 1-3 (whose cells straddle octants along the axes and diagonals): +2.0 %;
+// Morton order inside the octant, 4 x 8 cells, the triangle cut directly, Gray-code order of the octants: -0.1 ... -0.8 % against this.
+// (1-ulp reciprocals are plenty for a bin: results do not depend on the binning.)
 __device__ __forceinline__ uint32_t dir_bin(f3 d) {
-    float inv = __builtin_amdgcn_rcpf(fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + 1e-30f);    // (1 ulp is plenty for a bin: results do not depend on the binning)
-    float px = d.x * inv, py = d.y * inv;
-    if (d.z < 0.f) {
-        float qx = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
-        float qy = (1.f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
-        px = qx; py = qy;
-    }
-    int ix = min(15, max(0, (int)((px * 0.5f + 0.5f) * 16.f)));
-    int iy = min(15, max(0, (int)((py * 0.5f + 0.5f) * 16.f)));
-    // Morton interleave of two 4-bit numbers: spread each over the even bits (abcd -> 0a0b0c0d), then or
-    uint32_t x = (uint32_t)ix, y = (uint32_t)iy;
-    x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
-    y = (y | (y << 2)) & 0x33u; y = (y | (y << 1)) & 0x55u;
-    return x | (y << 1);
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const float inv = __builtin_amdgcn_rcpf(ax + ay + az + 1e-30f);
+    const float a = ax * inv, b = ay * inv;
+    const float v = b * __builtin_amdgcn_rcpf(1.f - a + 1e-30f);
+    const int iu = min(7, (int)(a * 8.f)), iv0 = min(3, (int)(v * 4.f));
+    const int iv = (iu & 1) ? 3 - iv0 : iv0;
+    const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+    return (oct << 5) | ((uint32_t)iu << 2) | (uint32_t)iv;
 }
 
 // Diagnostic build (-DIRIS_PHASE_TIMING, tools/diag_phases.py): shader cycles every workgroup spends in the phases of a tile, summed over
