@@ -77,3 +77,22 @@ def test_two_rank_bake_equals_single_process(oracle_mod):
     (Ld,) = oracle_mod.bake(sc, em, g["prim_position"], g["prim_normal"], 4, seed=9, stream=0, pix_id=ids)
     a, b = oracle_mod.bake(sc, em, g["prim_position"], g["prim_normal"], 4, wo=-g["rays_d"], roughness=0.412, seed=9, stream=3, pix_id=ids)
     np.testing.assert_array_equal(full, np.stack([Ld, a, b]))
+
+
+def test_block_order_equals_sorting_the_valid_rows():
+    """bake_shading.primary_hits lists the valid pixels block by block through a permutation of the raster that is computed once and kept
+    (no sort per view): the same list as sorting the valid rows by block key, for the full image and for a rank's stripes."""
+    from iris_amd import bake_shading as bs, sharding as sh
+    H, W, block = 37, 53, 8
+    g = torch.Generator().manual_seed(0)
+    for pixel_ids in (None, sh.local_pixel_ids(H, W, 3, 1, stripe=4)):
+        n = H * W if pixel_ids is None else pixel_ids.numel()
+        for _ in range(3):                                   # (several "views": the second and third come from the cache)
+            valid = torch.rand(n, generator=g) < 0.7
+            perm = bs._block_order(n, pixel_ids, W, block, torch.device("cpu"))
+            sel = perm[valid[perm]]
+            rows = torch.nonzero(valid).reshape(-1)
+            pix = rows if pixel_ids is None else pixel_ids[rows]
+            y, x = pix // W, pix % W
+            key = ((y // block) * ((W + block - 1) // block) + x // block) * (block * block) + (y % block) * block + x % block
+            assert torch.equal(sel, rows[torch.argsort(key)])
