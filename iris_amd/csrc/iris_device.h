@@ -47,45 +47,92 @@ __device__ __forceinline__ void normal_space(f3 n, f3& t, f3& b) {
 __device__ __forceinline__ f3 to_world(f3 l, f3 t, f3 b, f3 n) {
     return mk3((l.x * t.x + l.y * b.x) + l.z * n.x, (l.x * t.y + l.y * b.y) + l.z * n.y, (l.x * t.z + l.y * b.z) + l.z * n.z);
 }
-// sin/cos of phi in [0, 2*pi] with a fully specified IEEE operation sequence (Cody-Waite reduction by pi/4 octants +
-// the classic single-precision minimax polynomials; no fma, no libm), so that the CPU oracle's "device arithmetic"
-// mode reproduces it bit for bit.  |error| <= ~1.2e-7 absolute, i.e. the same class as libm / torch's SLEEF.
+// sin/cos of x in [0, 2*pi] with a fully specified IEEE operation sequence, so that the CPU oracle's "device arithmetic" mode reproduces it bit
+// for bit: quadrant j = int(x * 2/pi + 0.5), z = x - j * pi/2 in DOUBLE (one fma), the two kernels as double Horner chains (explicit fma), one
+// rounding to f32.  Double because that is the cheap way to a (practically) correctly rounded result on this chip -- v_fma_f64 issues at the rate of
+// the 4-cycle f32 class, and the f32-only Cody-Waite version of rounds 1-3 (~1 ulp) accounted for 14 of the 15 sample flips the HIP path had
+// on top of the libm restatement's against the reference (profiles/r4_flip_attribution.json).  Exhaustively over the 2^24 Philox outputs, phi =
+// 2 pi u: equal to the correctly rounded sin / cos for all but 2e-5 of the inputs; equal to torch-CPU's for 95.1 % (the correctly rounded value: 95.1 %,
+// glibc's sinf / cosf: 95.0 %; the old sequence: 80-85 %).
+// FIRST_QUADRANT: the caller guarantees x <= pi/2 + a few ulps (a polar angle): the same values from two selects instead of six.
+template <bool FIRST_QUADRANT = false>
 __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
-    int j = (int)(x * 1.27323954473516f);  // 4/pi
-    j = (j + 1) & ~1;
-    const float y = (float)j;
-    const float z = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    const float zz = z * z;
-    const float ps = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
-    const float pc = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
-    const int q = (j >> 1) & 3;
-    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
-    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+    const int j = (int)(x * 0.636619772367581343f + 0.5f);
+    const double z = fma(-(double)j, 1.57079632679489661923, (double)x);     // |z| <= pi/4 (+ rounding of the quadrant choice)
+    const double zz = z * z;
+    double p = 2.7249902524065394e-06;                                         // (sin z / z - 1) / z^2, |error| < 3e-11 on the interval
+    p = fma(p, zz, -0.0001984008661425884); p = fma(p, zz, 0.00833333187464819); p = fma(p, zz, -0.16666666663855825);
+    const float ps = (float)fma(z * zz, p, z);
+    double q = -2.723710465738025e-07;                                         // (cos z - 1) / z^2, |error| < 4e-13
+    q = fma(q, zz, 2.4799861845569796e-05); q = fma(q, zz, -0.0013888885090442048); q = fma(q, zz, 0.04166666663738883); q = fma(q, zz, -0.4999999999996389);
+    const float pc = (float)fma(zz, q, 1.0);
+    if (FIRST_QUADRANT) {   // j is 0 or 1
+        s = j == 0 ? ps : pc;
+        c = j == 0 ? pc : -ps;
+        return;
+    }
+    const int k = j & 3;
+    s = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
+    c = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
 }
-// utils/ops.py:32-44 angle2xyz given sin(theta), cos(theta) and phi
-__device__ __forceinline__ f3 angle2xyz_sc(float st, float ct, float phi) {
-    float sp, cp;
+// asin / acos on [0, 1] with a fully specified IEEE operation sequence (explicit fmaf, IEEE sqrtf, an integer-seeded Newton reciprocal):
+// the reference evaluates sin / cos of the ROUNDED polar angle theta = asin(sqrt(u0)) / acos(sqrt(c2)) (model/brdf.py:28, :50-51), and near grazing
+// cos(theta) inherits theta's rounding (6e-8 absolute) -- a closed form of cos(asin s) does not, and the sampled direction then differs from the
+// reference's in every bit below that.  So theta itself is computed, as accurately as f32 allows: |x| < 0.5: x + x z P(z), z = x^2; otherwise
+// pi/2 - 2 asin(sqrt z), z = (1 - x) / 2, with the square root's rounding error carried (r + rl) and the subtraction from pi/2 compensated
+// (hi / lo parts, Fast2Sum).  Exhaustively over the 2^24 Philox outputs u0: equal to the correctly rounded asin(sqrt u0) for 98.5 % of the inputs,
+// never more than 1 ulp off; equal to torch-CPU's asin for 94.1 % (the correctly rounded value: 94.9 %, glibc's asinf: 90.4 %).
+__device__ __forceinline__ float spec_asin_poly(float z) {   // (asin(sqrt z) / sqrt z - 1) / z on [0, 0.25], |error| < 4e-9
+    float p = 0.033805747f;
+    p = fmaf(p, z, 0.01707786f); p = fmaf(p, z, 0.031116156f); p = fmaf(p, z, 0.04459803f); p = fmaf(p, z, 0.07500099f);
+    return fmaf(p, z, 0.16666666f);
+}
+__device__ __forceinline__ float spec_half_rcp(float r) {    // 0.5 / r to ~2e-4 relative (scales a 6e-8 correction): integer estimate + two Newton steps
+    float x = __uint_as_float(0x7EF311C7u - __float_as_uint(r));
+    x = x * fmaf(-r, x, 2.0f);
+    x = x * fmaf(-r, x, 2.0f);
+    return 0.5f * x;
+}
+constexpr float kPio2Hi = 1.57079637050628662109375f, kPio2Lo = -4.37113900018624283e-8f;   // pi/2 = hi + lo
+// ACOS = false: asin(x); true: acos(x).  x in [0, 1] (a NaN stays a NaN).
+template <bool ACOS>
+__device__ __forceinline__ float spec_asin_acos(float x) {
+    const bool small = x < 0.5f;
+    const float z = small ? x * x : (1.0f - x) * 0.5f;
+    const float r = small ? x : sqrtf(z);
+    const float e = small ? 0.0f : fmaf(-r, r, z);                 // z - r^2, exact
+    const float rl = e * spec_half_rcp(fmaxf(r, 1e-20f));           // sqrt(z) = r + rl
+    const float m = r * z, pz = spec_asin_poly(z);
+    const float b = fmaf(m, pz, rl);                                // asin(r + rl) = r + b
+    // the branch that subtracts from pi/2 (asin: x >= 0.5 with k = 2; acos: x < 0.5 with k = 1)
+    const float k = ACOS ? 1.0f : 2.0f;
+    const float t = fmaf(-k, r, kPio2Hi);
+    const float err = fmaf(-k, r, kPio2Hi - t);                    // (pi/2_hi - k r) - t, exact (Fast2Sum: pi/2_hi >= k r)
+    const float far = t + fmaf(-k, b, err + kPio2Lo);
+    const float near = ACOS ? 2.0f * (r + b) : fmaf(m, pz, r);      // (asin, x < 0.5: rl = 0, one rounding)
+    return (small != ACOS) ? near : far;
+}
+// utils/ops.py:32-44 angle2xyz(theta, phi): theta in [0, pi/2], phi in [0, 2 pi]
+__device__ __forceinline__ f3 angle2xyz(float theta, float phi) {
+    float st, ct, sp, cp;
+    spec_sincos<true>(theta, st, ct);
     spec_sincos(phi, sp, cp);
     return t_normalize(mk3(st * cp, st * sp, ct));
 }
 
-// model/brdf.py:20-34 diffuse_sampler.  theta = asin(sqrt(u0)): sin(theta) = s = fl(sqrt(u0)) and
-// cos(theta) = sqrt((1-s)(1+s)) -- the same function of the ROUNDED s the reference evaluates through
-// asin/sin/cos, without the transcendental round trip (differs by <= ~1e-7 absolute).
+// model/brdf.py:20-34 diffuse_sampler: theta = asin(sqrt(u0)), phi = 2 pi u1
 __device__ __forceinline__ f3 diffuse_sampler(float u0, float u1, f3 n, f3 t, f3 b) {
-    float s = sqrtf(u0);
-    float c = sqrtf(fmaxf((1.f - s) * (1.f + s), 0.f));
-    f3 l = angle2xyz_sc(s, c, kTwoPi * u1);
+    const float theta = spec_asin_acos<false>(sqrtf(u0));
+    f3 l = angle2xyz(theta, kTwoPi * u1);
     return to_world(l, t, b, n);
 }
 
-// model/brdf.py:36-59 specular_sampler.  theta = acos(sqrt(c2)): cos = cs = fl(sqrt(c2)), sin = sqrt((1-cs)(1+cs)).
+// model/brdf.py:36-59 specular_sampler: theta = acos(sqrt(c2)), c2 = (1 - u0) / (u0 (alpha^2 - 1) + 1)
 __device__ __forceinline__ f3 specular_sampler(float u0, float u1, float rough, f3 wo, f3 n, f3 t, f3 b) {
     float alpha = rough * rough;
     float c2 = (1.f - u0) / (u0 * (alpha * alpha - 1.f) + 1.f);
-    float cs = sqrtf(c2);
-    float sn = sqrtf(fmaxf((1.f - cs) * (1.f + cs), 0.f));
-    f3 l = angle2xyz_sc(sn, cs, kTwoPi * u1);
+    const float theta = spec_asin_acos<true>(sqrtf(c2));
+    f3 l = angle2xyz(theta, kTwoPi * u1);
     f3 wh = to_world(l, t, b, n);
     float s = 2.f * t_dot(wo, wh);
     return t_normalize(mk3(s * wh.x - wo.x, s * wh.y - wo.y, s * wh.z - wo.z));
@@ -121,9 +168,12 @@ __device__ __forceinline__ SpecW specular_weights(f3 wi, f3 wo, f3 n, float roug
     return r;
 }
 
-// ---- Philox4x32-10 (perf-mode uniforms): counter=(idx_lo,idx_hi,stream,0) key=(seed_lo,seed_hi) ----
-__device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float& u0, float& u1) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream, c3 = 0u;
+// ---- Philox4x32-10 (perf-mode uniforms): counter = (block_lo, block_hi, stream, 0), key = (seed_lo, seed_hi); one block holds the uniform pairs of
+// TWO consecutive samples: sample idx = (pixel * spp + sample) reads block idx >> 1 and takes outputs (c0, c1) if idx is even, (c2, c3) if odd.
+// (Rounds 1-3 ran one block per sample and threw c2, c3 away.)  Still a pure function of (seed, idx, stream): independent of tiling and sharding.
+struct Philox4 { uint32_t c0, c1, c2, c3; };
+__device__ __forceinline__ Philox4 philox_block(uint64_t seed, uint64_t block, uint32_t stream) {
+    uint32_t c0 = (uint32_t)block, c1 = (uint32_t)(block >> 32), c2 = stream, c3 = 0u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -136,8 +186,16 @@ __device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t 
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     }
-    u0 = (float)(c0 >> 8) * 5.9604644775390625e-08f;
-    u1 = (float)(c1 >> 8) * 5.9604644775390625e-08f;
+    Philox4 o; o.c0 = c0; o.c1 = c1; o.c2 = c2; o.c3 = c3;
+    return o;
+}
+__device__ __forceinline__ void philox_pick(const Philox4& b, uint64_t idx, float& u0, float& u1) {
+    const bool odd = (idx & 1ull) != 0ull;
+    u0 = (float)((odd ? b.c2 : b.c0) >> 8) * 5.9604644775390625e-08f;
+    u1 = (float)((odd ? b.c3 : b.c1) >> 8) * 5.9604644775390625e-08f;
+}
+__device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float& u0, float& u1) {
+    philox_pick(philox_block(seed, idx >> 1, stream), idx, u0, u1);
 }
 
 // ---- VoxelSLF (model/slf.py) and SLFEmitter tables (model/emitter.py) as laid out in HBM ----

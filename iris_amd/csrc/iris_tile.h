@@ -110,7 +110,11 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
         };
         auto ret = [&](const Hit& h) { retire(my_r, h); };
         __builtin_amdgcn_s_setprio(IRIS_PRIO_C);
-        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc, s_stack + tid, ovf, &ts, fetch, prepare, ret);
+        // The per-lane stack addresses are derived from a FRESH copy of the thread index: as values live across the whole tile (sampling and shading
+        // included) hipcc spills them when another phase needs the registers -- and then reloads them from scratch in front of every push and pop.
+        uint32_t tid_c = threadIdx.x;
+        asm volatile("" : "+v"(tid_c));
+        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc, s_stack + tid_c, tid_c, ovf, &ts, fetch, prepare, ret);
         __builtin_amdgcn_s_setprio(IRIS_PRIO_D);
         IRIS_PHASE_MARK(4);      // wave 0's own traversal; 2 (below) also counts its wait for the slowest wave of the tile
     }

@@ -47,18 +47,19 @@ template <int LDS_DEPTH, bool GLOBAL_OVF = false>
 struct Stack {
     lds_u32* lds;   // &s_stack[threadIdx.x]
     uint32_t* ovf;  // GLOBAL_OVF: the workgroup's slab (wave-uniform: stays in scalar registers; the lane offset is added at the rare use)
+    uint32_t tid;   // threadIdx.x as the caller derived it for THIS traversal (tile kernels: a fresh value per phase, see tile_sort_trace)
     uint32_t spill[GLOBAL_OVF ? 1 : kStackCapacity - LDS_DEPTH];
     int sp;
     __device__ __forceinline__ void push(uint32_t v) {
         if (sp < LDS_DEPTH) lds[sp * kBlock] = v;
-        else if (GLOBAL_OVF) ovf[(uint32_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock + threadIdx.x] = v;
+        else if (GLOBAL_OVF) ovf[(uint32_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock + tid] = v;
         else spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)] = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
         if (sp < LDS_DEPTH) return lds[sp * kBlock];
-        if (GLOBAL_OVF) return ovf[(uint32_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock + threadIdx.x];
+        if (GLOBAL_OVF) return ovf[(uint32_t)min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1) * kBlock + tid];
         return spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)];
     }
 };
@@ -281,7 +282,7 @@ template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
     RayState r;
     ray_begin(sc, r, o, d);
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0; st.tid = threadIdx.x;
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
@@ -331,13 +332,13 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 #endif
 constexpr int kRefillMin = IRIS_REFILL_MIN;
 template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire>
-__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
+__device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t tid, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
                                              Retire retire) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(sc, r, r.o, r.d);
     r.cur = kEmptyRef;
-    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0;
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0; st.tid = tid;
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
     int max_sp = 0;

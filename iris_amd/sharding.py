@@ -42,21 +42,27 @@ class MapGatherer:
     __call__(local_maps (M, n_local, 3) in local_pixel_ids order) -> (M, H*W, 3) or None.  The returned tensor is the gatherer's own buffer:
     it is overwritten by the next call."""
 
-    def __init__(self, H, W, world, rank, n_maps, device, dtype=torch.float32, mode="all_gather", stripe=STRIPE_ROWS, group=None):
+    def __init__(self, H, W, world, rank, n_maps, device, dtype=torch.float32, mode="all_gather", stripe=STRIPE_ROWS, group=None, force_collective=False):
         if mode not in ("gather", "all_gather"):
             raise ValueError("mode must be 'gather' or 'all_gather'")
         self.H, self.W, self.world, self.rank, self.M, self.stripe, self.group, self.mode = H, W, world, rank, n_maps, stripe, group, mode
         self.device = torch.device(device)
+        if self.device.type == "cuda" and dtype != torch.float32:
+            raise ValueError("MapGatherer: device maps must be float32 (iris_unstripe_maps reads and writes f32)")
+        # force_collective: a world of ONE still goes through the send buffer, the collective and the permutation (bench.py IRIS_BENCH_FORCE_PG=1,
+        # tests/test_rccl_world1.py: RCCL, dist.gather with a list of views, all_gather_into_tensor and iris_unstripe_maps on an RCCL-written buffer
+        # exercised on a one-GPU box)
+        self.collective = world > 1 or bool(force_collective)
         self.n_local = int(stripe_rows(H, world, rank, stripe).numel()) * W
         self.n_max = max_local_pixels(H, W, world, stripe)
-        self.receives = world > 1 and (mode == "all_gather" or rank == 0)
-        self.send = torch.zeros(n_maps, self.n_max, 3, device=self.device, dtype=dtype) if world > 1 else None
+        self.receives = self.collective and (mode == "all_gather" or rank == 0)
+        self.send = torch.zeros(n_maps, self.n_max, 3, device=self.device, dtype=dtype) if self.collective else None
         self.recv = torch.empty(world, n_maps, self.n_max, 3, device=self.device, dtype=dtype) if self.receives else None
         self.full = torch.empty(n_maps, H * W, 3, device=self.device, dtype=dtype) if self.receives else None
         self._ids = None          # host path: per-rank image pixel ids, built on first use
 
     def __call__(self, local_maps):
-        if self.world == 1:
+        if not self.collective:
             return local_maps
         M, n_local, C = local_maps.shape
         if (M, n_local, C) != (self.M, self.n_local, 3):
@@ -84,9 +90,9 @@ class MapGatherer:
         return self.full
 
 
-def gather_maps(local_maps, H, W, world, rank, stripe=STRIPE_ROWS, group=None, mode="all_gather"):
+def gather_maps(local_maps, H, W, world, rank, stripe=STRIPE_ROWS, group=None, mode="all_gather", force_collective=False):
     """One-shot form of MapGatherer (allocates its buffers for this call; loops over views should keep a MapGatherer).
     local_maps: (M, n_local, 3) rows in local_pixel_ids order -> (M, H*W, 3) full maps (mode "gather": on rank 0, None elsewhere)."""
-    if world == 1:
+    if world == 1 and not force_collective:
         return local_maps
-    return MapGatherer(H, W, world, rank, local_maps.shape[0], local_maps.device, local_maps.dtype, mode, stripe, group)(local_maps)
+    return MapGatherer(H, W, world, rank, local_maps.shape[0], local_maps.device, local_maps.dtype, mode, stripe, group, force_collective)(local_maps)

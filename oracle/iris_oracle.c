@@ -164,8 +164,10 @@ static inline v3 to_world(v3 l, v3 t, v3 b, v3 n) {
  * mode 0 (default): the literal restatement above/below (libm asinf/acosf/sinf/cosf/powf) -- this is what is pinned
  *                   against the reference's golden vectors.
  * mode 1          : the same algorithm with the transcendental round trips replaced by the exactly specified IEEE
- *                   operation sequences the HIP kernels use (iris_amd/csrc/iris_device.h): sin(asin(s)) = s,
- *                   cos(asin(s)) = sqrt((1-s)(1+s)), cos(acos(c)) = c, sin(acos(c)) = sqrt((1-c)(1+c)), a Cody-Waite +
+ *                   operation sequences the HIP kernels use (iris_amd/csrc/iris_device.h): a specified asin / acos on
+ *                   [0, 1] (spec_asin_acos: explicit fmaf, IEEE sqrtf, an integer-seeded Newton reciprocal; within 1 ulp
+ *                   of the correctly rounded value and equal to it for 98.5 % of the 2^24 Philox outputs), a double-precision
+ *                   (explicit fma, practically correctly rounded)
  *                   polynomial sincos, x^5 by multiplication, and the kernels' fixed reduction order for the mean over
  *                   spp.  Mode 1 exists so that GPU results can be compared BIT FOR BIT at any size (the SLF / emitter
  *                   lookups are discontinuous, so 1-ulp differences in a direction flip rare samples by O(1)); it is
@@ -173,22 +175,64 @@ static inline v3 to_world(v3 l, v3 t, v3 b, v3 n) {
 static int g_mode = 0;
 ORC_API void orc_set_mode(int m) { g_mode = m; }
 ORC_API int orc_get_mode(void) { return g_mode; }
+/* Attribution studies (tools/attribute_flips.py): in mode 1, undo single substitutions -- bit 0: libm asinf / acosf for the polar angle, bit 1: libm
+ * sinf / cosf of the polar angle, bit 2: libm sinf / cosf of the azimuth, bit 3: powf for x^5 -- to see which one a disagreement with the reference comes from. */
+static int g_undo = 0;
+ORC_API void orc_set_undo(int m) { g_undo = m; }
 
+/* spec_sincos of iris_device.h, operation for operation: quadrant reduction and both kernels in double (explicit fma), one rounding to f32 */
 static inline void spec_sincos(float x, float *s, float *c) {
-    int j = (int)(x * 1.27323954473516f);
-    j = (j + 1) & ~1;
-    const float y = (float)j;
-    const float z = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    const float zz = z * z;
-    const float ps = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
-    const float pc = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
-    const int q = (j >> 1) & 3;
-    *s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
-    *c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+    const int j = (int)(x * 0.636619772367581343f + 0.5f);
+    const double z = fma(-(double)j, 1.57079632679489661923, (double)x);
+    const double zz = z * z;
+    double p = 2.7249902524065394e-06;
+    p = fma(p, zz, -0.0001984008661425884); p = fma(p, zz, 0.00833333187464819); p = fma(p, zz, -0.16666666663855825);
+    const float ps = (float)fma(z * zz, p, z);
+    double q = -2.723710465738025e-07;
+    q = fma(q, zz, 2.4799861845569796e-05); q = fma(q, zz, -0.0013888885090442048); q = fma(q, zz, 0.04166666663738883); q = fma(q, zz, -0.4999999999996389);
+    const float pc = (float)fma(zz, q, 1.0);
+    const int k = j & 3;
+    *s = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
+    *c = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
 }
-static inline v3 angle2xyz_sc(float st, float ct, float phi) {
-    float sp, cp;
-    spec_sincos(phi, &sp, &cp);
+/* spec_asin_acos of iris_device.h, operation for operation (x in [0, 1]) */
+static inline float as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float spec_asin_poly(float z) {
+    float p = 0.033805747f;
+    p = fmaf(p, z, 0.01707786f); p = fmaf(p, z, 0.031116156f); p = fmaf(p, z, 0.04459803f); p = fmaf(p, z, 0.07500099f);
+    return fmaf(p, z, 0.16666666f);
+}
+static inline float spec_half_rcp(float r) {
+    float x = as_f32(0x7EF311C7u - as_u32(r));
+    x = x * fmaf(-r, x, 2.0f);
+    x = x * fmaf(-r, x, 2.0f);
+    return 0.5f * x;
+}
+static const float PIO2_HI = 1.57079637050628662109375f, PIO2_LO = -4.37113900018624283e-8f;
+static inline float spec_asin_acos(float x, int acos_) {
+    const int small = x < 0.5f;
+    const float z = small ? x * x : (1.0f - x) * 0.5f;
+    const float r = small ? x : sqrtf(z);
+    const float e = small ? 0.0f : fmaf(-r, r, z);
+    const float rl = e * spec_half_rcp(fmaxf(r, 1e-20f));
+    const float m = r * z, pz = spec_asin_poly(z);
+    const float b = fmaf(m, pz, rl);
+    const float k = acos_ ? 1.0f : 2.0f;
+    const float t = fmaf(-k, r, PIO2_HI);
+    const float err = fmaf(-k, r, PIO2_HI - t);
+    const float far_ = t + fmaf(-k, b, err + PIO2_LO);
+    const float near_ = acos_ ? 2.0f * (r + b) : fmaf(m, pz, r);
+    return (small != (acos_ != 0)) ? near_ : far_;
+}
+ORC_API void orc_spec_asin_acos(const float *x, int64_t n, int acos_, float *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = spec_asin_acos(x[i], acos_);
+}
+/* angle2xyz through the specified sincos (theta in [0, pi/2]: the first-quadrant selects of the kernel give the same values) */
+static inline v3 angle2xyz_spec(float theta, float phi) {
+    float st, ct, sp, cp;
+    if (g_undo & 2) { st = sinf(theta); ct = cosf(theta); } else spec_sincos(theta, &st, &ct);
+    if (g_undo & 4) { sp = sinf(phi); cp = cosf(phi); } else spec_sincos(phi, &sp, &cp);
     return t_normalize(v3_make(st * cp, st * sp, ct));
 }
 
@@ -205,9 +249,7 @@ static inline v3 diffuse_sampler(float u0, float u1, v3 n) {
     float phi = TWO_PI_F * u1;
     v3 l, t, b;
     if (g_mode == 1) {
-        float s = sqrtf(u0);
-        float c = sqrtf(fmaxf((1.f - s) * (1.f + s), 0.f));
-        l = angle2xyz_sc(s, c, phi);
+        l = angle2xyz_spec((g_undo & 1) ? asinf(sqrtf(u0)) : spec_asin_acos(sqrtf(u0), 0), phi);
     } else {
         float theta = asinf(sqrtf(u0));
         l = angle2xyz(theta, phi);
@@ -234,9 +276,7 @@ static inline v3 specular_sampler(float u0, float u1, float rough, v3 wo, v3 n) 
     float phi = TWO_PI_F * u1;
     v3 l, t, b;
     if (g_mode == 1) {
-        float cs = sqrtf(c2);
-        float sn = sqrtf(fmaxf((1.f - cs) * (1.f + cs), 0.f));
-        l = angle2xyz_sc(sn, cs, phi);
+        l = angle2xyz_spec((g_undo & 1) ? acosf(sqrtf(c2)) : spec_asin_acos(sqrtf(c2), 1), phi);
     } else {
         float theta = acosf(sqrtf(c2));
         l = angle2xyz(theta, phi);
@@ -261,7 +301,7 @@ static inline float G1_GGX_Schlick(float NoV, float eta) {
     return 1.f / (NoV * (1.f - k) + k);
 }
 static inline float pow5(float x) {
-    if (g_mode == 1) { float x2 = x * x; return x2 * x2 * x; }
+    if (g_mode == 1 && !(g_undo & 8)) { float x2 = x * x; return x2 * x2 * x; }
     return powf(x, 5.f);
 }
 
@@ -886,7 +926,8 @@ ORC_API void orc_ray_intersect(const orc_scene *sc, const float *xs, const float
 
 /* ============================================================================================
  * Philox4x32-10 counter RNG (perf-mode uniforms; integer work, must match the HIP kernel bit for bit)
- *   counter = (idx_lo, idx_hi, stream, 0), key = (seed_lo, seed_hi); u0=(c0>>8)*2^-24, u1=(c1>>8)*2^-24
+ *   one block holds the uniform pairs of two consecutive samples: block = idx >> 1, counter = (block_lo, block_hi, stream, 0),
+ *   key = (seed_lo, seed_hi); idx even: u0=(c0>>8)*2^-24, u1=(c1>>8)*2^-24; idx odd: the same from (c2, c3)
  * ========================================================================================== */
 static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     for (int r = 0; r < 10; ++r) {
@@ -898,10 +939,12 @@ static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 static inline void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float *u0, float *u1) {
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream, 0u};
+    const uint64_t blk = idx >> 1;
+    const int o = (int)(idx & 1u) * 2;
+    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), stream, 0u};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    *u0 = (float)(c[0] >> 8) * 5.9604644775390625e-08f;
-    *u1 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;
+    *u0 = (float)(c[o] >> 8) * 5.9604644775390625e-08f;
+    *u1 = (float)(c[o + 1] >> 8) * 5.9604644775390625e-08f;
 }
 ORC_API void orc_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream, int64_t n, float *u2) {
     for (int64_t i = 0; i < n; ++i) philox_u2(seed, idx0 + (uint64_t)i, stream, u2 + i * 2, u2 + i * 2 + 1);
