@@ -9,6 +9,12 @@ secondary ray traced AND shaded.  N>1 shards the pixels of the SAME view over th
     python bench.py --gpus N --steps K --warmup W        (N > 1: starts one worker process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Host synchronisation: the primary pass of a view (`bake_shading.primary_hits`) compacts the valid pixels with a boolean mask, which synchronises the
+host ONCE per view (the pixel count is needed to size the launch); everything else of a step is stream-ordered.  It is inside the timed region.
+
+After the timed region rank 0 CHECKS the numbers it timed: a pixel subsample of the LAST timed view's maps (all lobes) against the CPU oracle in
+device-arithmetic mode, bit for bit (`parity_check`; a mismatch makes the run fail with exit code 3).
+
 Rank 0 prints ONE JSON line.  `roofline` prices the timed kernel (bake_view_kernel: all lobes of a view behind one launch) against three
 calibrated roofs -- VALU issue, the vector-memory (L1 / TA) path, HBM-side bytes -- and names the binding one.
 `cpu_baseline` is the CPU oracle (a port of the same algorithm, oracle/) timed on a bounded pixel sample of the same workload.
@@ -27,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "pmc_r3.json"
+PMC_FILE = "pmc_r4.json"
 N_SIMD, N_CU = 1024, 256
 
 
@@ -140,6 +146,10 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=0, help="debug: the rank whose stripes --emulate-world bakes")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="iris_debug_set tuning option (experiments), e.g. bvh_max_leaf=2")
     ap.add_argument("--variant", type=int, default=0, help="bake kernel: 0 auto (tile-sorted), 1 pixel-per-wave, 2 tile-sorted")
+    ap.add_argument("--parity-pixels", type=int, default=8192, help="pixels of the last timed view checked bit for bit against the device-arithmetic CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the cpu_baseline sample (the median is reported; each takes --cpu-seconds / repeats)")
+    ap.add_argument("--scene-scaling", type=str, default="", help="comma-separated triangle counts: also measure the 7-lobe bake on rooms of these sizes (extras.scene_scaling), e.g. 200000,1000000,3000000,6000000")
+    ap.add_argument("--scene-scaling-views", type=int, default=8)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -151,6 +161,11 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    # stdout carries exactly ONE line, the JSON: everything else written to file descriptor 1 from here on -- RCCL prints a five-line version banner to the
+    # C stdout when its first communicator is created -- goes to stderr; the line itself is written to the saved descriptor at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
     # one process per GPU.  (IRIS_BENCH_BACKEND=gloo lets a box with fewer GPUs than ranks exercise the N>1 control flow by
     # sharing devices; it is a functional check only, never a measurement.)
@@ -164,13 +179,23 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    # IRIS_BENCH_FORCE_PG=1: a world of ONE still creates the process group and sends every view through the collective (RCCL load,
+    # dist.gather / all_gather_into_tensor, iris_unstripe_maps on the received buffer) -- the N > 1 code path exercised on a one-GPU box
+    force_pg = os.environ.get("IRIS_BENCH_FORCE_PG", "0") == "1"
+    have_pg = world > 1 or force_pg
+    if have_pg:
         import datetime
         to = datetime.timedelta(seconds=args.collective_timeout)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=to)   # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, timeout=to, world_size=world, rank=rank)   # RCCL over xGMI
         else:
-            dist.init_process_group(backend, timeout=to)
+            dist.init_process_group(backend, timeout=to, world_size=world, rank=rank)
 
     from iris_amd import _lib as L
     from iris_amd import bake_shading as bs
@@ -193,11 +218,12 @@ def main():
     n_maps = (1 if 0 in lobes else 0) + 2 * sum(1 for l in lobes if l > 0)
     one_launch = args.variant == 0 and not args.per_lobe
 
-    gather_stream = torch.cuda.Stream(device=dev) if (world > 1 and not by_views) else None
-    gatherer = sh.MapGatherer(H, W, world, rank, n_maps, dev, mode=args.gather) if gather_stream is not None else None     # buffers allocated once per run
+    gather_stream = torch.cuda.Stream(device=dev) if (have_pg and not by_views) else None
+    gatherer = sh.MapGatherer(H, W, world, rank, n_maps, dev, mode=args.gather, force_collective=force_pg) if gather_stream is not None else None     # buffers allocated once per run
     fail_rank, fail_step = int(os.environ.get("IRIS_BENCH_FAIL_RANK", "-1")), int(os.environ.get("IRIS_BENCH_FAIL_STEP", "1"))   # (tests: a rank dying mid-run)
     n_step = [0]
     last = [None]
+    last_g = [None]   # the last view's primary-hit tensors (parity_check)
     ev_view = []     # (start, end, rays) HIP events around every bake_view_kernel launch of the timed region, on the launch stream
     ev_gather = []   # the same around the all_gather + permutation (N > 1)
 
@@ -258,13 +284,14 @@ def main():
         else:
             full = maps
         last[0] = maps
+        last_g[0] = (g, view)
         return rays, full
 
     def sync():
         if gather_stream is not None:
             torch.cuda.current_stream().wait_stream(gather_stream)
         torch.cuda.synchronize()
-        if world > 1:
+        if have_pg:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -287,14 +314,14 @@ def main():
     rays_t = torch.tensor([rays_local], device=dev, dtype=torch.float64)
     ranks_seen = torch.ones(1, device=dev, dtype=torch.float64)
     per_rank = [dt_local]
-    if world > 1:
+    gather_ok = None
+    if have_pg:
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         per_rank = [float(x.item()) for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
         dist.all_reduce(ranks_seen, op=dist.ReduceOp.SUM)
-        gather_ok = None
         if gatherer is not None:
             # the gathered image of the last view holds exactly the ranks' local maps: an order-independent integer checksum (the float bits summed
             # as int64, wrapping) of what every rank sent, reduced over the ranks, against the same checksum of what a receiving rank holds
@@ -319,10 +346,11 @@ def main():
                                                                                                                         f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 {args.gather} per view"),
                    "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"],
                            "sah_cost": round(info["sah_cost"], 3), "build_seconds": round(info["build_seconds"], 2)}},
-        "multi_gpu": {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks_seen": int(ranks_seen.item()), "per_rank_ms_per_step": [round(x / max(args.steps, 1) * 1e3, 3) for x in per_rank],
+        "multi_gpu": {"backend": (("rccl" if backend == "nccl" else backend) if have_pg else None), "process_group": have_pg, "forced_at_world_1": bool(force_pg and world == 1),
+                      "ranks_seen_by_all_reduce": int(ranks_seen.item()) if have_pg else None, "per_rank_ms_per_step": [round(x / max(args.steps, 1) * 1e3, 3) for x in per_rank],
                       "gather_ms": round(float(np.mean([a.elapsed_time(b) for a, b in ev_gather])), 3) if ev_gather else None,
                       "gather_overlapped": gatherer is not None, "collective": (args.gather if gatherer is not None else None),
-                      "gathered_image_matches_what_the_ranks_sent": gather_ok if world > 1 else None},
+                      "gathered_image_matches_what_the_ranks_sent": gather_ok},
     }
 
     if rank == 0 and not args.no_roofline and one_launch and ev_view:
@@ -337,7 +365,7 @@ def main():
         nP = g["position"].shape[0]
         sel = torch.arange(nP, device=dev)
         sel = sel[(sel // 8192) % 16 == 3] if nP > 16 * 8192 else sel      # every 16th block of 8192 consecutive pixels (whole tiles: real coherence)
-        stats = torch.zeros(16, device=dev, dtype=torch.int64)
+        stats = torch.zeros(20, device=dev, dtype=torch.int64)
         for l in lobes:
             if l == 0:
                 bs.bake_diffuse(scene, emitter, g["position"][sel], g["normal"][sel], spp, seed=0, stream_id=0, pix_id=g["pix_id"][sel], stats=stats)
@@ -353,7 +381,11 @@ def main():
                 "simd_lane_util_tris": round(st[2] / max(st[4] * 64, 1), 3),
                 "drain": {"frac_of_node_iterations": round(st[10] / max(st[3], 1), 4), "lane_util": round(st[9] / max(st[10] * 64, 1), 3)},
                 "stack_depth_frac_gt_8_12_16": [round(st[5] / st[0], 4), round(st[6] / st[0], 5), round(st[7] / st[0], 6)],
-                "top_of_tree_visits_per_ray_lt_21_85_341_1365_nodes": [round(st[k] / st[0], 2) for k in (11, 12, 13, 14)]}
+                "top_of_tree_visits_per_ray_lt_21_85_341_1365_nodes": [round(st[k] / st[0], 2) for k in (11, 12, 13, 14)],
+                # how much of the node work a wave does TOGETHER (the scalar-top-of-tree question, EXPERIMENTS.md round 4): node steps in which >= 32 lanes sit at one
+                # node of one octant table, as a share of all node steps / the visits made in them, as a share of all visits / their SIMD lane utilisation
+                "shared_node_steps": {"share_of_node_steps": round(st[15] / max(st[3], 1), 4), "share_of_node_visits": round(st[16] / max(st[1], 1), 4),
+                                      "lanes_at_the_shared_node": round(st[16] / max(st[15], 1), 1), "steps_with_every_lane_at_it": round(st[17] / max(st[3], 1), 4)}}
         assert 0 <= st[7] <= st[6] <= st[5] <= st[0] and st[3] * 64 >= st[1], "instrumented counters violate their invariants"
         # (b) counters of the same kernel from the committed rocprofv3 passes, refused when stale
         pj, src = load_pmc(rays_per_launch, info["node_bytes"])
@@ -385,27 +417,33 @@ def main():
             # HBM side: bytes that left the L2s (FETCH_SIZE + WRITE_SIZE, KB), against the 8 TB/s HBM peak
             traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
             hbm_ach = traffic / pr * rate / 1e9
+            prof_rate = pr / (pj["duration"]["avg_ns"] * 1e-9)                    # rays / s of the PROFILED launches (their own duration)
+            lane_util = c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"] * 64, 1)
+            valu_prof = quads_per_ray * prof_rate / 1e9
             roofs = {
-                "valu": {"achieved": round(valu_ach, 1), "peak": round(valu_peak, 1), "unit": "G VALU issue quad-cycles/s", "frac": round(valu_ach / valu_peak, 4),
-                         "frac_in_the_profiled_run": round(quads_per_ray * pr / (pj["duration"]["avg_ns"] * 1e-9) / 1e9 / valu_peak, 4),
-                         "frac_note": "frac = the profiled issue quad-cycles per ray x THIS run's ray rate; frac_in_the_profiled_run = the same counters over the profiled launch's own duration; "
-                                      "pure instruction streams top out at 0.88 (v_fma_f32, dual issue) ... 0.94-0.97 (4- and 8-cycle classes): profiles/r3_counter_calibration.json",
+                "valu": {"achieved": round(valu_prof, 1), "peak": round(valu_peak, 1), "unit": "G VALU issue quad-cycles/s", "frac": round(valu_prof / valu_peak, 4),
+                         "frac_with_this_runs_ray_rate": round(valu_ach / valu_peak, 4),
+                         "useful_lane_frac": round(valu_prof / valu_peak * lane_util, 4),
+                         "frac_note": "frac = counters and duration of the SAME profiled launches (recomputable from profiles/" + PMC_FILE + "); frac_with_this_runs_ray_rate = the profiled issue quad-cycles "
+                                      "per ray x THIS run's ray rate (the views and the clock differ between runs); useful_lane_frac = frac x SIMD lane utilisation: the share of the VALU "
+                                      "LANE-cycles that did work; pure instruction streams top out at 0.88 (v_fma_f32, dual issue) ... 0.94-0.97 (4- and 8-cycle classes): profiles/r3_counter_calibration.json",
                          "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "issue_quads_per_ray": round(quads_per_ray, 1),
                          "dual_issued_share_of_instructions": round(2 * c["SQ_ACTIVE_INST_VALU2"] / c["SQ_INSTS_VALU"], 3), "profiled_clock_GHz": round(clock / 1e9, 3),
-                         "simd_lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"] * 64, 1), 3)},
-                "l1_ta": {"achieved": round(ta_ach, 1), "peak": round(ta_peak, 1), "unit": "G TA cycles/s", "frac": round(ta_ach / ta_peak, 4),
+                         "simd_lane_utilisation": round(lane_util, 3), "wave_cycles_waiting": round(c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)},
+                "l1_ta": {"achieved": round(ta_ach * prof_rate / rate, 1), "peak": round(ta_peak, 1), "unit": "G TA cycles/s", "frac": round(ta_ach * prof_rate / rate / ta_peak, 4),
                           "wave_loads_per_ray": round(loads_per_ray, 2), "lines_per_wave_load": round(lines_per_load, 1), "ta_cycles_per_wave_load": round(cyc_load, 1),
                           "l1_hit": round(1 - l1_miss, 3), "l2_hit": round(1 - l2_miss, 3), "ta_busy_counter": round(c["TA_TA_BUSY_sum"] / N_CU / (c["GRBM_GUI_ACTIVE"] / 8), 3),
                           "td_busy_counter": round(c["TD_TD_BUSY_sum"] / N_CU / (c["GRBM_GUI_ACTIVE"] / 8), 3)},
-                "hbm": {"achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
-                        "bytes_per_ray": round(traffic / pr, 1), "note": "raw FETCH_SIZE + WRITE_SIZE: calibrated on known traffic (profiles/r3_counter_calibration.json) FETCH_SIZE reads 1.05 x the bytes of random 64-B record fetches "
+                "hbm": {"achieved": round(hbm_ach * prof_rate / rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach * prof_rate / rate / HBM_PEAK_GBS, 4),
+                        "bytes_per_ray": round(traffic / pr, 1), "read_bytes_per_ray": round(c["FETCH_SIZE"] * 1024.0 / pr, 1), "write_bytes_per_ray": round(c["WRITE_SIZE"] * 1024.0 / pr, 1),
+                        "write_note": "the maps are 0.17 B/ray; the rest of the writes are the per-ray slots (sampled direction, GGX weights, hit) travelling through the workgroup's slab", "note": "raw FETCH_SIZE + WRITE_SIZE: calibrated on known traffic (profiles/r3_counter_calibration.json) FETCH_SIZE reads 1.05 x the bytes of random 64-B record fetches "
                                 "(this kernel's pattern) and 0.50 x those of a wide coalesced stream (the guide's case); were every fetch of the stream kind the fraction would be twice this"},
             }
             bound = max(roofs, key=lambda k: roofs[k]["frac"])
         rl = {"kernel": "bake_view_kernel<Q8> (all lobes of a view, one persistent launch)", "launch_ms": round(avg_ms, 3), "launches": len(ms),
               "rays_per_launch": int(rays_per_launch), "mrays_per_s_kernel": round(rate / 1e6, 1), "pmc_source": src,
               "pmc_file": "profiles/" + PMC_FILE if pj else None, "roofs": roofs, "traffic": traffic,
-              "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "algorithmic_GBps": round(bytes_per_ray * rate / 1e9, 1),
+              "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "algorithmic_GBps_cache_served_exceeds_hbm_peak": round(bytes_per_ray * rate / 1e9, 1),
               "algorithmic_note": "SURVEY 8(d) byte model; these bytes are served by L1 / L2 / Infinity Cache, so the figure exceeds the HBM peak and is not a roof",
               "work_per_ray": work}
         if roofs:
@@ -414,12 +452,96 @@ def main():
             rl.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
         result["roofline"] = rl
 
+    # ---- the timed output checked: a pixel subsample of the LAST timed view, every lobe, against the CPU oracle in device-arithmetic mode, bit for bit
+    parity_failed = False
+    if rank == 0 and args.parity_pixels > 0 and one_launch and last_g[0] is not None:
+        import oracle
+        oracle.build()
+        g, view_checked = last_g[0]
+        osc = oracle.Scene(room["vertices"], room["faces"])
+        oslf = oracle.VoxelSLF(slf_np["inds"], slf_np["radiance"], slf_np["voxel_min"], slf_np["voxel_max"])
+        oem = oracle.SLFEmitter(emi_np["is_emitter"], emi_np["emitter_radiance"], emi_np["emitter_area"], oslf)
+        P = g["position"].shape[0]
+        pick = torch.linspace(0, P - 1, min(args.parity_pixels, P), device=dev).round().long().unique()
+        pos, nrm, wo = (g[k][pick].cpu().numpy() for k in ("position", "normal", "wo"))
+        pid = g["pix_id"][pick].cpu().numpy().astype(np.int32)
+        timed_maps = last_maps[:, g["sel"][pick]].cpu().numpy()            # what the timed step wrote for these pixels (n_maps, n, 3)
+        t0c = time.perf_counter()
+        mism, m, worst = [], 0, 0
+        with oracle.device_arithmetic():
+            for l in lobes:
+                kw = {} if l == 0 else {"wo": wo, "roughness": np.float32(rough[l - 1])}
+                ref = oracle.bake(osc, oem, pos, nrm, spp, seed=0, stream=l, pix_id=pid, **kw)
+                for k, r in enumerate(ref):
+                    bad = int((timed_maps[m + k].view(np.int32) != r.view(np.int32)).any(1).sum())
+                    if bad:
+                        mism.append({"lobe": l, "map": k, "pixels": bad})
+                    worst = max(worst, bad)
+                m += len(ref)
+        parity_failed = bool(mism)
+        result["parity_check"] = {"bit_exact": not parity_failed, "pixels": int(pick.numel()), "maps": m, "samples_per_pixel_and_lobe": spp, "rays_checked": int(pick.numel()) * spp * len(lobes),
+                                  "view": int(view_checked % args.views), "against": "oracle.bake in device-arithmetic mode (oracle/iris_oracle.c, mode 1) on the same primary hits, Philox seed 0",
+                                  "what": "the maps written by the LAST TIMED step (not a re-bake), evenly spaced valid pixels", "mismatches": mism[:8], "oracle_seconds": round(time.perf_counter() - t0c, 2)}
+        del osc, oem, oslf
+
+    if rank == 0 and world == 1 and not args.no_extras and one_launch:
+        # ---- extras with their own events: SURVEY 8(d)'s n_lobes = 1 figure (the diffuse lobe alone: fully incoherent secondary rays) and the reference's own
+        # spp mix (bake_shading.py:90,143: diffuse 256, specular 64 / 128 x 5), on views of the same sequence
+        def timed_views(lobe_ids, spps, n_views=4):
+            ev, rays = [], 0
+            for i in range(n_views + 1):
+                c2w_i = synth.camera(H, W, (i * args.views) // (n_views + 1), n_views=args.views)[1]
+                xs_i, ds_i = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w_i, False, device=dev)
+                gi = bs.primary_hits(scene, xs_i[pix_local], ds_i[pix_local], pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bs.bake_lobes(scene, emitter, gi["position"], gi["normal"], gi["wo"], [None if l == 0 else rough[l - 1] for l in lobe_ids], spps, seed=0, stream_ids=lobe_ids, pix_id=gi["pix_id"])
+                e1.record()
+                if i:                       # (the first view warms up)
+                    ev.append((e0, e1)); rays += gi["position"].shape[0] * sum(spps)
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in ev]
+            return {"mrays_per_s": round(rays / (sum(ms) * 1e-3) / 1e6, 1), "kernel_ms_by_view": [round(x, 2) for x in ms], "rays_per_view": int(rays / len(ms)), "lobes": lobe_ids, "spp": spps,
+                    "timing": "HIP events around the one bake_view_kernel launch of each view"}
+        result.setdefault("extras", {})
+        result["extras"]["n_lobes_1_diffuse_only"] = timed_views([0], [spp])
+        result["extras"]["reference_spp_mix"] = timed_views([0, 1, 2, 3, 4, 5, 6], [256, 64, 128, 128, 128, 128, 128])
+
+    if rank == 0 and world == 1 and args.scene_scaling:
+        # ---- extras.scene_scaling: the 7-lobe bake on rooms of other sizes (the node table exists once per ray octant: 8 x 64 B x nodes)
+        import argparse as _ap
+        rows = []
+        for tris in [int(x) for x in args.scene_scaling.split(",")]:
+            a2 = _ap.Namespace(**vars(args)); a2.tris = tris
+            t0b = time.perf_counter()
+            _, _, _, sc2, em2 = build_workload(a2, dev)
+            inf2 = sc2.info()
+            ev, rays = [], 0
+            for i in range(args.scene_scaling_views + 1):
+                c2w_i = synth.camera(H, W, (i * args.views) // (args.scene_scaling_views + 1), n_views=args.views)[1]
+                xs_i, ds_i = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w_i, False, device=dev)
+                gi = bs.primary_hits(sc2, xs_i[pix_local], ds_i[pix_local], pixel_ids=pix_local, image_width=W if args.pixel_block else None, block=max(args.pixel_block, 1))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bs.bake_lobes(sc2, em2, gi["position"], gi["normal"], gi["wo"], [None if l == 0 else rough[l - 1] for l in lobes], [spp] * len(lobes), seed=0, stream_ids=lobes, pix_id=gi["pix_id"])
+                e1.record()
+                if i:
+                    ev.append((e0, e1)); rays += gi["position"].shape[0] * spp * len(lobes)
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in ev]
+            rows.append({"triangles": inf2["n_triangles"], "nodes": inf2["n_nodes"], "node_table_MB": round(inf2["n_nodes"] * inf2["node_bytes"] * 8 / 1e6, 1), "depth": inf2["depth"],
+                         "build_seconds": round(inf2["build_seconds"], 2), "mrays_per_s": round(rays / (sum(ms) * 1e-3) / 1e6, 1), "kernel_ms_by_view": [round(x, 1) for x in ms],
+                         "setup_seconds": round(time.perf_counter() - t0b, 1)})
+            del sc2, em2
+            torch.cuda.empty_cache()
+        result.setdefault("extras", {})["scene_scaling"] = rows
+
     if rank == 0 and world == 1 and not args.no_extras:
         # (before the CPU baseline: its OpenMP team keeps spinning for a while after the last parallel region, and this loop of small launches is
         #  bound by the host thread that issues them -- on a box whose cgroup grants exactly as many CPUs as that team has threads)
         # ---- extras: BASELINE configs[4] (train_brdf_crf / train_emitter inner loop: differentiable one-bounce path tracer, SPP 32) on the same scene
         from tools import bench_pt_single
-        result["extras"] = {"cfg5_path_tracing_single": bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2)}
+        result.setdefault("extras", {})["cfg5_path_tracing_single"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2)
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----
@@ -464,24 +586,39 @@ def main():
             calib[th] = round(n / dtc / 1e6, 3)
         threads = max(calib, key=calib.get)
         oracle.set_num_threads(threads)
-        n_px = int(min(len(pos), max(threads * 8, calib[threads] * 1e6 * args.cpu_seconds / (spp * len(lobes)))))
-        n, dtc = cpu_run(n_px)
+        reps = max(1, args.cpu_repeats)
+        n_px = int(min(len(pos), max(threads * 8, calib[threads] * 1e6 * args.cpu_seconds / reps / (spp * len(lobes)))))
+        runs = [cpu_run(n_px) for _ in range(reps)]                        # repeated, the median reported
+        n = runs[0][0]
+        times = sorted(r[1] for r in runs)
+        dtc = times[len(times) // 2]
         cpu_model = "unknown"
         try:
             cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
         except Exception:     # noqa
             pass
-        result["cpu_baseline"] = {"value": round(n / dtc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "cpu_model": cpu_model, "hw_threads": ncpu,
-                                  "sched_getaffinity": n_aff, "cgroup_cpu_max": cpu_max, "mrays_per_s_per_thread": round(n / dtc / 1e6 / threads, 4),
-                                  "calibration_mrays_per_s_by_threads": calib,
-                                  "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, {dtc:.1f} s, OpenMP x{threads}"}
+        cgroup_cpus = None
+        try:
+            q, per = cpu_max.split()[:2]
+            cgroup_cpus = None if q == "max" else round(float(q) / float(per), 2)
+        except Exception:     # noqa
+            pass
+        result["cpu_baseline"] = {"value": round(n / dtc / 1e6, 3), "unit": "Mrays/s", "cores": threads, "threads": threads, "cgroup_cpus": cgroup_cpus, "kind": "port", "cpu_model": cpu_model,
+                                  "hw_threads": ncpu, "sched_getaffinity": n_aff, "cgroup_cpu_max": cpu_max, "mrays_per_s_per_thread": round(n / dtc / 1e6 / threads, 4),
+                                  "calibration_mrays_per_s_by_threads": calib, "repeats": reps, "seconds_by_repeat": [round(r[1], 2) for r in runs],
+                                  "cores_note": "`cores` = OpenMP threads used (the fastest of the calibrated counts); the box's cgroup quota is `cgroup_cpus`",
+                                  "sample": f"{n_px} evenly spaced valid pixels of the same view x SPP={spp} x lobes {lobes} = {n} rays, literal (libm) mode, {reps} repeats, median {dtc:.1f} s, OpenMP x{threads}"}
         result["gpu_over_cpu"] = round(value / (n / dtc / 1e6), 1)
 
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    if have_pg:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
+    if parity_failed:
+        print("bench.py: parity_check FAILED -- the timed maps differ from the device-arithmetic oracle: " + json.dumps(result["parity_check"]["mismatches"]), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

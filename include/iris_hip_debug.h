@@ -23,10 +23,11 @@ enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED =
  *   src_next (P*spp) int64, nullable: per sample, the radiance-table row eval_emitter read: -2 - emitter ordinal for an emitter
  *            triangle, the VoxelSLF row for the radiance cache, -1 for empty space or a miss (parity bookkeeping: a sample whose
  *            (tri_next, src_next) differs from the oracle's is a discrete "flip", everything else differs by rounding only);
- *   stats    nullable device uint64[16]: when given, an INSTRUMENTED build of the kernel (4 waves/SIMD) adds
+ *   stats    nullable device uint64[20]: when given, an INSTRUMENTED build of the kernel (4 waves/SIMD) adds
  *            {rays, node visits, triangle tests, wave-level node steps, wave-level triangle steps, rays whose stack exceeded
  *            8 / 12 / 16 entries, tail sum (pixel-per-wave), node visits / wave-level node steps while a tile drains,
- *            node visits with node index < 21 / 85 / 341 / 1365, 0};
+ *            node visits with node index < 21 / 85 / 341 / 1365, wave-level node steps in which >= 32 of the lanes at a node sit at
+ *            the SAME node of the same octant table / the lanes that share it / the steps in which all of them do, 0, 0};
  *   variant  IRIS_BAKE_*.  All variants and the instrumented builds return identical bits. */
 IRIS_API int iris_debug_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                             int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,
@@ -45,6 +46,8 @@ IRIS_API int iris_debug_bake_specular(const iris_scene *, const iris_emitter *, 
  *   "pt_tile_min": smallest batch the path-tracing stages route through the tile-sorted kernel
  * NOT thread-safe: plain process-wide globals that iris_scene_create / the launches read.  Set them before creating handles, from one thread. */
 IRIS_API int iris_debug_set(const char *key, long long value);
+/* The compiler flags this library was built with (iris_amd/csrc/Makefile embeds them): part of the stamp that ties a counter profile to a build. */
+IRIS_API const char *iris_debug_build_flags(void);
 
 #ifdef __cplusplus
 }

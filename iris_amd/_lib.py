@@ -50,6 +50,7 @@ PROTOTYPES = {
     "iris_debug_bake_diffuse": [_P, _P, _P, _P, _P, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
     "iris_debug_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
     "iris_debug_set": [C.c_char_p, C.c_longlong],
+    "iris_debug_build_flags": [],
     "iris_bake_view": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _U64, _P, _P, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_unstripe_maps": [_P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P],
@@ -84,7 +85,7 @@ PROTOTYPES = {
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
 
 _lib = None
 
@@ -106,10 +107,12 @@ def lib():
 
 
 def source_hash():
-    """sha256 over the kernel sources and the ABI headers: stamps profiles (tools/pmc_summary.py) so that bench.py can refuse counters
-    that were taken on other kernels."""
+    """sha256 over the kernel sources, the ABI headers and the compiler flags embedded in the LOADED library (iris_debug_build_flags: -fno-slp-vectorize,
+    the scheduler strategy and the -D tuning overrides are worth several per cent): stamps profiles (tools/pmc_summary.py) so that bench.py can
+    refuse counters that were taken on other kernels or on another build of the same sources."""
     import hashlib
     h = hashlib.sha256()
+    h.update(lib().iris_debug_build_flags())
     root = os.path.dirname(_HERE)
     files = sorted(os.path.join("iris_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip", ".cpp")))
     files += [os.path.join("include", "iris_hip.h"), os.path.join("include", "iris_hip_debug.h")]

@@ -57,7 +57,7 @@ def bake_diffuse(scene, emitter, position, normal, spp=SPP_DIFFUSE, u2=None, see
     """Ld_ of bake_shading.py:108-123 for all P valid pixels: mean over spp of Le along cosine-sampled rays.
     u2: optional (P*spp,2) uniforms in the reference's order (parity mode); otherwise in-kernel Philox.
     want_tri: also return the per-sample hit triangle (P*spp,) int64.
-    Diagnostics (routed through include/iris_hip_debug.h): want_src -> per-sample radiance-table row; stats -> zeroed int64[16]
+    Diagnostics (routed through include/iris_hip_debug.h): want_src -> per-sample radiance-table row; stats -> zeroed int64[20]
     device tensor for an instrumented launch; variant -> a specific kernel.  Returns Ld [, tri] [, src]."""
     position, normal, P, dev, u2, pix_id, tri = _common(scene, emitter, position, normal, spp, u2, pix_id, want_tri)
     Ld = torch.empty(P, 3, device=dev, dtype=torch.float32)
@@ -285,8 +285,9 @@ class MapWriter:
         self.pool = ThreadPoolExecutor(max_workers=max(1, min(n_maps, os.cpu_count() or 4)), thread_name_prefix="maps")
         self.k = 0
 
-    def submit(self, files, maps_dev):
-        """maps_dev: (n_maps, H, W, 3) f32 on the device (R,G,B), produced on the current stream; files: n_maps paths."""
+    def submit(self, files, maps_dev, on_written=None):
+        """maps_dev: (n_maps, H, W, 3) f32 on the device (R,G,B), produced on the current stream; files: n_maps paths.
+        on_written: called (on a writer thread) once ALL of this view's files are complete on disk -- refine_shading's per-view resume marker."""
         exr, (H, W) = self.exr, self.img_hw
         full, tail = exr.scanline_blocks_torch(maps_dev, self.compression)
         if self.bufs is None:
@@ -311,7 +312,14 @@ class MapWriter:
             tmp = path + ".part"
             exr.write_exr_blocks(tmp, H, W, self.compression, hfull[j], htail[j], pool=chunks)
             os.replace(tmp, path)
-        self.busy[i] = [self.pool.submit(write, f, j) for j, f in enumerate(files)]
+        futs = [self.pool.submit(write, f, j) for j, f in enumerate(files)]
+        if on_written is not None:
+            def finish():
+                for f in futs:
+                    f.result()                              # (a failed write re-raises here and the marker is not written)
+                on_written()
+            futs = futs + [self.pool.submit(finish)]        # queued behind the writes it waits for
+        self.busy[i] = futs
 
     def close(self):
         for fs in self.busy:
@@ -390,6 +398,9 @@ def main(argv=None):
         files = output_files(args.output, im_id)
         if not args.overwrite and all(os.path.exists(f) for f in files):
             continue
+        marker = os.path.join(args.output, "diffuse", "{:03d}.refined".format(im_id))
+        if os.path.exists(marker):
+            os.remove(marker)                               # the view is baked again: refine_shading --resume must not take the new files for refined ones
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
         # per-view Philox key: the reference's torch.rand stream advances from view to view, so its Monte-Carlo noise is independent
         # across the training views; keyed on the view id (not on the rank), so that results do not depend on how views are sharded

@@ -20,8 +20,8 @@ struct BakeArgs {
     int64_t P; int spp; uint64_t seed; uint32_t stream_id; float rough;
     float* out0; float* out1; int64_t* tri_next;
     int64_t* src_next;          // diagnostics (iris_hip_debug.h): per sample, the radiance-table row that was read (eval_emitter1's src)
-    unsigned long long* stats;  // instrumented launches only: 16 slots {rays, node visits, tri tests, wave node iters, wave leaf iters, rays with
-                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, [11..14] node visits with index < 21 / 85 / 341 / 1365}
+    unsigned long long* stats;  // instrumented launches only: 20 slots {rays, node visits, tri tests, wave node iters, wave leaf iters, rays with
+                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, [11..14] node visits with index < 21 / 85 / 341 / 1365, [15..17] wave node iterations with >= 32 lanes at one node / those lanes / iterations with ALL lanes at one node}
     // tile kernels only
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
@@ -61,7 +61,13 @@ template <bool SPEC>
 __device__ __forceinline__ void sample_lobe(const BakeArgs& a, int64_t p, int s, f3 n, f3 w, f3 t, f3 b, uint64_t base, f3& wi, float& g0, float& g1) {
     float u0, u1;
     if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
-    else philox_u2(a.seed, base + (uint64_t)s, a.stream_id, u0, u1);
+    else {
+        // (the ten round keys are wave-uniform: left to itself hipcc hoists them out of the sampling loop into 20 scalar registers it does not have and
+        //  reloads them from vector-register lanes every iteration; behind this barrier they are re-derived by scalar adds, which cost no vector issue)
+        uint32_t s_lo = (uint32_t)a.seed, s_hi = (uint32_t)(a.seed >> 32);
+        asm volatile("" : "+s"(s_lo), "+s"(s_hi));
+        philox_u2(((uint64_t)s_hi << 32) | s_lo, base + (uint64_t)s, a.stream_id, u0, u1);
+    }
     sample_dir<SPEC>(a, u0, u1, n, w, t, b, wi, g0, g1);
 }
 
@@ -126,6 +132,12 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
             uint32_t x = tp[k];
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 11 + k, (unsigned long long)x);
+        }
+        uint32_t sh[3] = {ts.shared_iters, ts.shared_lanes, ts.shared_all_iters};
+        for (int k = 0; k < 3; ++k) {
+            uint32_t x = sh[k];
+            for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+            if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 15 + k, (unsigned long long)x);
         }
         unsigned long long y = ts.max_steps64;
         for (int m = 1; m < 64; m <<= 1) y += __shfl_xor(y, m);
@@ -231,35 +243,6 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
         __syncthreads();
     }
 
-    // Perf-mode uniforms: one Philox4x32 block holds the pairs of two consecutive samples (iris_device.h), so the blocks are drawn in a pass of their
-    // own -- a lane takes samples 2q and 2q + 1 of the tile and parks each one's (u0, u1) in the sample's slot, which the sampling pass below reads back
-    // (8 B per ray through the workgroup's L1 / L2-resident slab, coalesced) -- instead of once per sample inside the sampling pass.  When two
-    // neighbouring tile rays do not share a block (an odd spp) the second draws its own.
-    if (!a.u2) {
-        uint32_t s_lo = (uint32_t)a.seed, s_hi = (uint32_t)(a.seed >> 32);
-        for (int r = 2 * tid; r < nr; r += 2 * kBlock) {
-            // (the ten round keys are wave-uniform: left to itself hipcc hoists them out of the loop into 20 scalar registers it does not have and
-            //  reloads them from vector-register lanes every iteration; behind this barrier they are re-derived by scalar adds, which cost no vector issue)
-            asm volatile("" : "+s"(s_lo), "+s"(s_hi));
-            const uint64_t seed = ((uint64_t)s_hi << 32) | s_lo;
-            const int pl = div_spp(r), s = r - pl * spp;
-            const int64_t p = p0 + pl;
-            const uint64_t i0 = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp + (uint64_t)s;
-            const Philox4 blk = philox_block(seed, i0 >> 1, a.stream_id);
-            float u0, u1;
-            philox_pick(blk, i0, u0, u1);
-            res[r] = make_float4(u0, u1, 0.f, 0.f);
-            if (r + 1 < nr) {
-                const int pl1 = div_spp(r + 1), s1 = r + 1 - pl1 * spp;
-                const int64_t p1 = p0 + pl1;
-                const uint64_t i1 = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p1] : p1) * (uint64_t)spp + (uint64_t)s1;
-                if ((i1 >> 1) == (i0 >> 1)) philox_pick(blk, i1, u0, u1);
-                else philox_pick(philox_block(seed, i1 >> 1, a.stream_id), i1, u0, u1);
-                res[r + 1] = make_float4(u0, u1, 0.f, 0.f);
-            }
-        }
-        __syncthreads();
-    }
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
     tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
         a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
@@ -267,14 +250,12 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
             const int pl = div_spp(r), s = r - pl * spp;
             const int64_t p = p0 + pl;
             const f3 n = ld3(a.nrm + p * 3), w = SPEC ? ld3(a.wo + p * 3) : mk3(0.f, 0.f, 1.f);
+            const uint64_t base = (uint64_t)(a.pix_id ? (int64_t)a.pix_id[p] : p) * (uint64_t)spp;
             f3 t, b;
             if (frames) { const float* f = s_frames + pl * 6; t = mk3(f[0], f[1], f[2]); b = mk3(f[3], f[4], f[5]); }
             else normal_space(n, t, b);
-            float u0, u1;
-            if (a.u2) { const float* up = a.u2 + (p * a.spp + s) * 2; u0 = up[0]; u1 = up[1]; }
-            else { const float4 q = res[r]; u0 = q.x; u1 = q.y; }          // parked by the Philox pass above
             f3 wi; float g0, g1;
-            sample_dir<SPEC>(a, u0, u1, n, w, t, b, wi, g0, g1);
+            sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
             res[r] = make_float4(wi.x, wi.y, wi.z, 0.f);
             if (SPEC) res_g[r] = make_float2(g1, g0);
             return dir_bin(wi);

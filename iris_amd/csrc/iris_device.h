@@ -55,16 +55,39 @@ __device__ __forceinline__ f3 to_world(f3 l, f3 t, f3 b, f3 n) {
 // 2 pi u: equal to the correctly rounded sin / cos for all but 2e-5 of the inputs; equal to torch-CPU's for 95.1 % (the correctly rounded value: 95.1 %,
 // glibc's sinf / cosf: 95.0 %; the old sequence: 80-85 %).
 // FIRST_QUADRANT: the caller guarantees x <= pi/2 + a few ulps (a polar angle): the same values from two selects instead of six.
+// (a double constant behind an optimisation barrier: it is materialised where it is used -- two scalar moves -- instead of being hoisted out of the
+//  sampling loop into a register pair that is then spilled to scratch and reloaded per sample)
+#ifndef IRIS_SINCOS_KD
+#define IRIS_SINCOS_KD 1
+#endif
+__device__ __forceinline__ double kd(double c) {
+#if IRIS_SINCOS_KD
+    asm volatile("" : "+s"(c));
+#endif
+    return c;
+}
 template <bool FIRST_QUADRANT = false>
 __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
+#ifdef IRIS_SINCOS_F32_EXPERIMENT    // (timing experiments only: the f32 sequence of rounds 1-3; different bits)
+    int j = (int)(x * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    const float y = (float)j;
+    const float z = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float zz = z * z;
+    const float ps = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
+    const float pc = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
+    const int q = (j >> 1) & 3;
+    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+#else
     const int j = (int)(x * 0.636619772367581343f + 0.5f);
-    const double z = fma(-(double)j, 1.57079632679489661923, (double)x);     // |z| <= pi/4 (+ rounding of the quadrant choice)
+    const double z = fma(-(double)j, kd(1.57079632679489661923), (double)x);     // |z| <= pi/4 (+ rounding of the quadrant choice)
     const double zz = z * z;
-    double p = 2.7249902524065394e-06;                                         // (sin z / z - 1) / z^2, |error| < 3e-11 on the interval
-    p = fma(p, zz, -0.0001984008661425884); p = fma(p, zz, 0.00833333187464819); p = fma(p, zz, -0.16666666663855825);
+    double p = kd(2.7249902524065394e-06);                                         // (sin z / z - 1) / z^2, |error| < 3e-11 on the interval
+    p = fma(p, zz, kd(-0.0001984008661425884)); p = fma(p, zz, kd(0.00833333187464819)); p = fma(p, zz, kd(-0.16666666663855825));
     const float ps = (float)fma(z * zz, p, z);
-    double q = -2.723710465738025e-07;                                         // (cos z - 1) / z^2, |error| < 4e-13
-    q = fma(q, zz, 2.4799861845569796e-05); q = fma(q, zz, -0.0013888885090442048); q = fma(q, zz, 0.04166666663738883); q = fma(q, zz, -0.4999999999996389);
+    double q = kd(-2.723710465738025e-07);                                         // (cos z - 1) / z^2, |error| < 4e-13
+    q = fma(q, zz, kd(2.4799861845569796e-05)); q = fma(q, zz, kd(-0.0013888885090442048)); q = fma(q, zz, kd(0.04166666663738883)); q = fma(q, zz, kd(-0.4999999999996389));
     const float pc = (float)fma(zz, q, 1.0);
     if (FIRST_QUADRANT) {   // j is 0 or 1
         s = j == 0 ? ps : pc;
@@ -74,6 +97,7 @@ __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
     const int k = j & 3;
     s = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
     c = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
+#endif
 }
 // asin / acos on [0, 1] with a fully specified IEEE operation sequence (explicit fmaf, IEEE sqrtf, an integer-seeded Newton reciprocal):
 // the reference evaluates sin / cos of the ROUNDED polar angle theta = asin(sqrt(u0)) / acos(sqrt(c2)) (model/brdf.py:28, :50-51), and near grazing
@@ -168,12 +192,12 @@ __device__ __forceinline__ SpecW specular_weights(f3 wi, f3 wo, f3 n, float roug
     return r;
 }
 
-// ---- Philox4x32-10 (perf-mode uniforms): counter = (block_lo, block_hi, stream, 0), key = (seed_lo, seed_hi); one block holds the uniform pairs of
-// TWO consecutive samples: sample idx = (pixel * spp + sample) reads block idx >> 1 and takes outputs (c0, c1) if idx is even, (c2, c3) if odd.
-// (Rounds 1-3 ran one block per sample and threw c2, c3 away.)  Still a pure function of (seed, idx, stream): independent of tiling and sharding.
-struct Philox4 { uint32_t c0, c1, c2, c3; };
-__device__ __forceinline__ Philox4 philox_block(uint64_t seed, uint64_t block, uint32_t stream) {
-    uint32_t c0 = (uint32_t)block, c1 = (uint32_t)(block >> 32), c2 = stream, c3 = 0u;
+// ---- Philox4x32-10 (perf-mode uniforms): counter=(idx_lo,idx_hi,stream,0) key=(seed_lo,seed_hi), idx = pixel * spp + sample; outputs c0, c1 are the
+// sample's (u0, u1).  (c2, c3 are a second pair, but nothing in these kernels can take it for free: a lane would have to sample two rays per block, and
+// both ways of arranging that -- the pairs drawn in a pass of their own, or a lane sampling rays 2q and 2q + 1 with the second pair parked in the ray's
+// slot -- measured SLOWER than drawing a block per sample, -2.5 % and -4 % of the view kernel, EXPERIMENTS.md round 4.)
+__device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float& u0, float& u1) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream, c3 = 0u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -186,16 +210,8 @@ __device__ __forceinline__ Philox4 philox_block(uint64_t seed, uint64_t block, u
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     }
-    Philox4 o; o.c0 = c0; o.c1 = c1; o.c2 = c2; o.c3 = c3;
-    return o;
-}
-__device__ __forceinline__ void philox_pick(const Philox4& b, uint64_t idx, float& u0, float& u1) {
-    const bool odd = (idx & 1ull) != 0ull;
-    u0 = (float)((odd ? b.c2 : b.c0) >> 8) * 5.9604644775390625e-08f;
-    u1 = (float)((odd ? b.c3 : b.c1) >> 8) * 5.9604644775390625e-08f;
-}
-__device__ __forceinline__ void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float& u0, float& u1) {
-    philox_pick(philox_block(seed, idx >> 1, stream), idx, u0, u1);
+    u0 = (float)(c0 >> 8) * 5.9604644775390625e-08f;
+    u1 = (float)(c1 >> 8) * 5.9604644775390625e-08f;
 }
 
 // ---- VoxelSLF (model/slf.py) and SLFEmitter tables (model/emitter.py) as laid out in HBM ----

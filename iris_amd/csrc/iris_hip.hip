@@ -55,6 +55,10 @@ extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     return IRIS_OK;
 }
 extern "C" IRIS_API const char* iris_version(void) { return "iris_hip 0.1 (gfx950)"; }
+#ifndef IRIS_BUILD_FLAGS
+#define IRIS_BUILD_FLAGS "unknown"
+#endif
+extern "C" IRIS_API const char* iris_debug_build_flags(void) { return IRIS_BUILD_FLAGS; }
 
 // ======================================================================================================
 // handles

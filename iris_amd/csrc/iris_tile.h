@@ -114,7 +114,11 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
         // included) hipcc spills them when another phase needs the registers -- and then reloads them from scratch in front of every push and pop.
         uint32_t tid_c = threadIdx.x;
         asm volatile("" : "+v"(tid_c));
-        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc, s_stack + tid_c, tid_c, ovf, &ts, fetch, prepare, ret);
+        // The same for the table bases (wave-uniform, scalar registers): fresh copies whose live range is the traversal -- otherwise the kernel-long values
+        // are spilled to vector-register lanes and read back (v_readlane + wait states) in front of the node / triangle loads of every visit.
+        SceneDev sc_c = sc;
+        asm volatile("" : "+s"(sc_c.nodes), "+s"(sc_c.tris), "+s"(sc_c.oct_stride));
+        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc_c, s_stack + tid_c, tid_c, ovf, &ts, fetch, prepare, ret);
         __builtin_amdgcn_s_setprio(IRIS_PRIO_D);
         IRIS_PHASE_MARK(4);      // wave 0's own traversal; 2 (below) also counts its wait for the slowest wave of the tile
     }

@@ -43,6 +43,13 @@ constexpr int kStackCapacity = kStackLds + kStackSpill;
 // pop() into one flat_load_dword (a vector-memory instruction with an aperture check, counted on vmcnt AND lgkmcnt) -- on the dependent
 // chain of every pop; with the qualified pointer it is a ds_read_b32 and the overflow a global_load behind a (rare) branch.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// (the table reads are addressed through address-space-1 pointers for the same reason: a table base that went through an optimisation barrier
+//  -- tile_sort_trace -- is no longer known to be global, and hipcc falls back to flat_load)
+//  (native vector types: HIP's float4 / uint4 are classes, and copying one out of an address-space-1 lvalue goes through a generic reference again)
+typedef uint32_t iris_u4v __attribute__((ext_vector_type(4)));
+typedef float iris_f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const iris_u4v glb_u4v;
+typedef __attribute__((address_space(1))) const iris_f4v glb_f4v;
 template <int LDS_DEPTH, bool GLOBAL_OVF = false>
 struct Stack {
     lds_u32* lds;   // &s_stack[threadIdx.x]
@@ -95,9 +102,9 @@ __device__ __forceinline__ void ray_xform(f3 o, f3 d, RayXf& x) {
 __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const RayXf& x, Hit& h) {
     const uint32_t base = (uint32_t)slot << 6;     // 32-bit byte offset from the (scalar) table base
     const char* tb = reinterpret_cast<const char*>(sc.tris);
-    const float4 X = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offx));
-    const float4 Y = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offy));
-    const float4 Z = *reinterpret_cast<const float4*>(tb + (size_t)(base + x.offz));
+    const iris_f4v X = *(glb_f4v*)(tb + (size_t)(base + x.offx));
+    const iris_f4v Y = *(glb_f4v*)(tb + (size_t)(base + x.offy));
+    const iris_f4v Z = *(glb_f4v*)(tb + (size_t)(base + x.offz));
     const int id = __float_as_int(Z.w);            // (every plane carries the index)
     const float Atz = Z.x - x.oz, Btz = Z.y - x.oz, Ctz = Z.z - x.oz;
     const float Ax = fmaf(-x.sx, Atz, X.x - x.ox), Ay = fmaf(-x.sy, Atz, Y.x - x.oy);
@@ -128,6 +135,10 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const Ray
                                   uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
 #define IRIS_HITKEY(tn, tf) ((tn) <= (tf) ? (tn) : INFINITY)
 
+__device__ __forceinline__ bool first_active_lane() {
+    unsigned long long m = __ballot(1);
+    return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
+}
 // Traversal statistics (instrumented builds only): per-lane counts, reduced by the caller.
 struct TraceStats {
     uint32_t nodes = 0;       // node visits of this lane
@@ -139,12 +150,16 @@ struct TraceStats {
     uint32_t drain_nodes = 0, drain_node_iters = 0; // trace_stream: the same two node counters while the ray list is exhausted (no refill)
     uint32_t top21 = 0, top85 = 0, top341 = 0, top1365 = 0;   // node visits with node index < 21 / 85 / 341 / 1365 (nodes are in breadth-first order:
                                                               // the first 1 + 4 + 16 (+ 64 (+ 256 (+ 1024))) nodes are the top 3 (4, 5, 6) levels of a full tree)
+    uint32_t shared_iters = 0, shared_lanes = 0, shared_all_iters = 0;   // wave node iterations in which >= 32 of the lanes at a node sit at the SAME node of the same
+                                                                          // octant table (counted by the first active lane), the lanes that share it, and the
+                                                                          // iterations in which every lane at a node does
+    __device__ __forceinline__ void count_shared(uint32_t cur, uint32_t oct_base) {   // called by the lanes at a node
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur), o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct_base);
+        const int n_same = __popcll(__ballot(cur == c0 && oct_base == o0)), n_all = __popcll(__ballot(1));
+        if (first_active_lane() && n_same >= 32) { shared_iters++; shared_lanes += (uint32_t)n_same; shared_all_iters += n_same == n_all; }
+    }
     __device__ __forceinline__ void count_top(uint32_t cur) { top21 += cur < 21u; top85 += cur < 85u; top341 += cur < 341u; top1365 += cur < 1365u; }
 };
-__device__ __forceinline__ bool first_active_lane() {
-    unsigned long long m = __ballot(1);
-    return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
-}
 
 // Wave-level phase scheduling.  A lane is in one of three states: at an internal node, at a leaf (k triangles tested so far),
 // or done.  The wave alternates a NODE phase and a LEAF phase; a phase ends when no lane needs it, or early when fewer than
@@ -192,8 +207,8 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // The node table exists once per ray octant (iris_hip.hip): the copy a ray reads holds the children in ITS front-to-back order (the order of
         // the binary splits the node was collapsed from) and, per axis, the plane it meets first in the "near" bytes -- so a visit selects no planes
         // by the ray's signs and sorts nothing.  32-bit byte offset from the (scalar) table base: one shift-add per visit.
-        const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)((r.cur << 6) + r.oct_base));
-        const uint4 hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
+        glb_u4v* n = (glb_u4v*)(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)((r.cur << 6) + r.oct_base));
+        const iris_u4v hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
         // per-axis: t(q) = q * 2^e * idir + (origin * idir - o * idir); the node stores 2^(e+24) as a float (see below)
         const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
@@ -293,7 +308,7 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
             if (n_node == 0) break;
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (at_node) {
-                if (COUNT) { ts->nodes++; ts->count_top(r.cur); if (first_active_lane()) ts->node_iters++; }
+                if (COUNT) { ts->nodes++; ts->count_top(r.cur); ts->count_shared(r.cur, r.oct_base); if (first_active_lane()) ts->node_iters++; }
                 node_step<LAYOUT>(sc, r, st);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }
@@ -373,7 +388,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
             if (at_node) {
-                if (COUNT) { ts->nodes++; ts->count_top(r.cur); if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
+                if (COUNT) { ts->nodes++; ts->count_top(r.cur); ts->count_shared(r.cur, r.oct_base); if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
                 node_step<LAYOUT>(sc, r, st);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }

@@ -58,17 +58,20 @@ class VoxelSLF(nn.Module):
         if self._h is None or self._h_device != device or not self._same(self._ver, iv):
             self.refresh()
             h = C.c_void_p()
-            on_dev = lambda t: t.is_cuda and t.device.index == (device.index if device.index is not None else torch.cuda.current_device())
+            # the device index resolved ONCE ('cuda' without an index = torch's current device): the same index decides whether the tensors are already
+            # there, which device torch makes current around the call, and which device the C side creates the tables on
+            idx = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0)
+            on_dev = lambda t: t.is_cuda and t.device.index == idx
             if device.type == "cuda" and on_dev(self.inds) and on_dev(self.radiance):
                 inds = self.inds.detach().to(torch.int64).contiguous()
                 rad = self.radiance.detach().to(torch.float32).contiguous().reshape(-1, 3)
-                with torch.cuda.device(device):
-                    L.check(L.lib().iris_slf_create_dev(L.ptr(inds), self.H, L.ptr(rad), rad.shape[0], self.voxel_min, self.voxel_max, device.index or 0, C.byref(h), L.stream()))
+                with torch.cuda.device(idx):
+                    L.check(L.lib().iris_slf_create_dev(L.ptr(inds), self.H, L.ptr(rad), rad.shape[0], self.voxel_min, self.voxel_max, idx, C.byref(h), L.stream()))
             else:
                 inds = np.ascontiguousarray(self.inds.detach().cpu().numpy(), dtype=np.int64)
                 rad = L.host_f32(self.radiance).reshape(-1, 3)
                 L.check(L.lib().iris_slf_create(inds.ctypes.data_as(C.c_void_p), self.H, rad.ctypes.data_as(C.c_void_p), rad.shape[0],
-                                                self.voxel_min, self.voxel_max, device.index or 0, C.byref(h)))
+                                                self.voxel_min, self.voxel_max, idx, C.byref(h)))
             self._h, self._h_device, self._ver, self._rver = h, device, iv, self._tver(self.radiance)
         elif need_radiance and not self._same(self._rver, self._tver(self.radiance)):
             rr = self.radiance.detach().to(device=device, dtype=torch.float32).contiguous()

@@ -165,28 +165,48 @@ def main(argv=None):
     # (refine_shading.py:126,172-173).  So a view's files existing says nothing about whether it has been refined: every view is rendered and
     # overwritten, unless --resume finds the sidecar a completed refine of that view left behind (keyed on what determines the result).
     import hashlib
-    ck = ""
-    if args.ckpt and os.path.exists(args.ckpt):
-        st = os.stat(args.ckpt); ck = "{}:{}:{}".format(os.path.abspath(args.ckpt), st.st_size, int(st.st_mtime))
-    run_key = hashlib.sha256(repr((args.material, ck, args.spp_diffuse, args.spp_specular, args.indir_depth, args.seed, args.res_scale, args.denoise,
-                                   tuple(img_hw))).encode()).hexdigest()[:16]
-    done = []
+    import json
+
+    def stamp(path):
+        """(absolute path, size, mtime in ns) of an input file or directory, or the path alone when it does not exist"""
+        if not path or not os.path.exists(path):
+            return (str(path),)
+        st = os.stat(path)
+        return (os.path.abspath(path), st.st_size, st.st_mtime_ns)
+    # run_key: everything that determines the refined maps -- the arguments AND the identity of every input file (mesh, SLF, emitters, cameras, material
+    # checkpoint: a changed file under an unchanged path is a different run)
+    run_key = hashlib.sha256(repr((args.material, stamp(args.ckpt), stamp(mesh_path), stamp(args.slf_path), stamp(args.emitter_path), stamp(args.cameras),
+                                   args.dataset, os.path.abspath(args.scene), args.spp_diffuse, args.spp_specular, args.indir_depth, args.seed, args.res_scale,
+                                   args.denoise, tuple(img_hw))).encode()).hexdigest()[:16]
+
+    def files_state(files):
+        return [[os.path.basename(f), os.stat(f).st_size, os.stat(f).st_mtime_ns] for f in files]
+
+    def refined(marker, files):
+        """the marker of a completed refine of this view, by this run_key, whose 13 files are still the ones it wrote (a re-bake replaces them)"""
+        try:
+            m = json.load(open(marker))
+            return m.get("run_key") == run_key and m.get("files") == files_state(files)
+        except Exception:     # noqa  (no marker, a marker of another format, a missing file)
+            return False
     for im_id in range(rank, len(views), world):
         files = output_files(args.output, im_id)
         marker = os.path.join(args.output, "diffuse", "{:03d}.refined".format(im_id))
-        if args.resume and os.path.exists(marker) and open(marker).read().strip() == run_key and all(os.path.exists(f) for f in files):
+        if args.resume and refined(marker, files):
             continue
         if os.path.exists(marker):
             os.remove(marker)
         torch.manual_seed(args.seed * 1000003 + im_id); torch.cuda.manual_seed(args.seed * 1000003 + im_id)     # the integrators draw with torch.rand
         xs, ds = cameras.view_rays(views[im_id], img_hw, device)
         out = refine_view(scene, emitter, material_net, xs, ds, args.spp_diffuse, args.spp_specular, args.indir_depth, batch_rays=args.batch_rays, denoiser=denoiser)
-        writer.submit(files, torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3))
-        done.append(marker)
-    writer.close()                                             # every file is on disk from here on
-    for marker in done:
-        with open(marker, "w") as fh:
-            fh.write(run_key + "\n")
+
+        def mark(marker=marker, files=files):              # on a writer thread, as soon as THIS view's 13 files are complete: a crash later loses only the views in flight
+            tmp = marker + ".part"
+            with open(tmp, "w") as fh:
+                json.dump({"run_key": run_key, "files": files_state(files)}, fh)
+            os.replace(tmp, marker)
+        writer.submit(files, torch.stack([out["diffuse"]] + [out[k][r] for r in range(N_ROUGHNESS) for k in ("specular0", "specular1")]).reshape(13, *img_hw, 3), on_written=mark)
+    writer.close()                                             # every file and every marker is on disk from here on
     torch.cuda.synchronize()
     print("[refine_shading] rank {}: {:.2f} s".format(rank, time.time() - start_time))
 

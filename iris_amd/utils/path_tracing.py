@@ -287,6 +287,8 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
             L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
                                     L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 0.0 if full else 1e-6, L.stream()))
             join = torch.cuda.Event(); join.record(side)
+        for t_side in (position, normal, wo, albedo, rough, metal, s1, s2, coef1, e1):
+            t_side.record_stream(side)     # an exception in a main-stream stage below must not hand these blocks back to the main-stream pool while the side kernel still reads them
         # BRDF sampling + next intersection (:384-391)
         s1b, s2b = nxt(N), nxt(N, 2)
         wi_b = torch.empty(N, 3, device=dev); pdf_b = torch.empty(N, device=dev); w_b = torch.empty(N, 3, device=dev)

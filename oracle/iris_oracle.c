@@ -14,9 +14,10 @@
  *     reference's own Python (tools/make_goldens.py -> tests/golden/ npz files).
  *   - a2 ray/mesh intersection: PARITY UNPINNED.  The reference delegates it to Mitsuba 3.5.0
  *     (cuda_ad_rgb / OptiX; environment.yml:14-15), whose source is not under /root/reference
- *     and which the reference has no test vectors for.  We restate Mitsuba 3's published
- *     triangle routine (Moeller-Trumbore as in mitsuba3 include/mitsuba/render/mesh.h
- *     `ray_intersect_triangle_impl`) and its Mesh::compute_surface_interaction conventions
+ *     and which the reference has no test vectors for.  OptiX's triangle test is closed; what is known
+ *     about it is that it is watertight, so the hit decision restated here is the published watertight test
+ *     (Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection", JCGT 2(1), 2013, section 3; tri_test
+ *     below), with Mitsuba 3's Mesh::compute_surface_interaction conventions for what is returned
  *     (si.p = barycentric interpolation, si.n = unit geometric normal, si.uv = (b1,b2) when the
  *     mesh carries no texcoords, t = +inf on a miss), anchored on the reference's call site
  *     utils/path_tracing.py:17-48.
@@ -926,8 +927,7 @@ ORC_API void orc_ray_intersect(const orc_scene *sc, const float *xs, const float
 
 /* ============================================================================================
  * Philox4x32-10 counter RNG (perf-mode uniforms; integer work, must match the HIP kernel bit for bit)
- *   one block holds the uniform pairs of two consecutive samples: block = idx >> 1, counter = (block_lo, block_hi, stream, 0),
- *   key = (seed_lo, seed_hi); idx even: u0=(c0>>8)*2^-24, u1=(c1>>8)*2^-24; idx odd: the same from (c2, c3)
+ *   counter = (idx_lo, idx_hi, stream, 0), key = (seed_lo, seed_hi); u0=(c0>>8)*2^-24, u1=(c1>>8)*2^-24
  * ========================================================================================== */
 static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     for (int r = 0; r < 10; ++r) {
@@ -939,12 +939,10 @@ static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 static inline void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, float *u0, float *u1) {
-    const uint64_t blk = idx >> 1;
-    const int o = (int)(idx & 1u) * 2;
-    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), stream, 0u};
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream, 0u};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    *u0 = (float)(c[o] >> 8) * 5.9604644775390625e-08f;
-    *u1 = (float)(c[o + 1] >> 8) * 5.9604644775390625e-08f;
+    *u0 = (float)(c[0] >> 8) * 5.9604644775390625e-08f;
+    *u1 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;
 }
 ORC_API void orc_philox_u2(uint64_t seed, uint64_t idx0, uint32_t stream, int64_t n, float *u2) {
     for (int64_t i = 0; i < n; ++i) philox_u2(seed, idx0 + (uint64_t)i, stream, u2 + i * 2, u2 + i * 2 + 1);

@@ -12,10 +12,10 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-def _run(*extra):
+def _run(*extra, env_extra=None, extras=True):
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--height", "120", "--width", "160", "--spp", "32", "--tris", "20000",
-           "--slf-res", "64", "--views", "4", "--cpu-seconds", "0.5", "--no-extras"] + list(extra)
-    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600)
+           "--slf-res", "64", "--views", "4", "--cpu-seconds", "0.5"] + ([] if extras else ["--no-extras"]) + list(extra)
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env_extra or {})))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly ONE line on stdout:\n" + r.stdout[-2000:]
@@ -37,7 +37,24 @@ def test_single_gpu_line():
     assert rf["pmc_source"] != "committed" and rf["bound"] is None and rf["frac"] is None and rf["traffic"] is None
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and "sample" in cb
-    assert d["multi_gpu"]["rccl_ranks_seen"] == 1 and d["multi_gpu"]["gather_ms"] is None
+    assert cb["threads"] == cb["cores"] and cb["repeats"] == 3 and len(cb["seconds_by_repeat"]) == 3 and "cgroup_cpus" in cb
+    mg = d["multi_gpu"]                      # no process group at N = 1: nothing about a backend is claimed
+    assert mg["backend"] is None and mg["process_group"] is False and mg["ranks_seen_by_all_reduce"] is None and mg["gather_ms"] is None
+    pc = d["parity_check"]                   # the timed maps themselves, against the device-arithmetic oracle
+    assert pc["bit_exact"] is True and pc["maps"] == 13 and pc["pixels"] >= 4096 and pc["mismatches"] == []
+    ex = d["extras"]
+    assert ex["n_lobes_1_diffuse_only"]["mrays_per_s"] > 0 and ex["reference_spp_mix"]["spp"] == [256, 64, 128, 128, 128, 128, 128]
+
+
+@pytest.mark.timeout(900)
+def test_forced_process_group_of_one_runs_rccl():
+    """IRIS_BENCH_FORCE_PG=1: RCCL's communicator, the gather of a view and the permutation of the received buffer execute on this one GPU"""
+    for collective in ("gather", "all_gather"):
+        d = _run("--gather", collective, env_extra={"IRIS_BENCH_FORCE_PG": "1"}, extras=False)
+        mg = d["multi_gpu"]
+        assert mg["backend"] == "rccl" and mg["process_group"] is True and mg["forced_at_world_1"] is True and mg["ranks_seen_by_all_reduce"] == 1
+        assert mg["collective"] == collective and mg["gather_ms"] is not None and mg["gathered_image_matches_what_the_ranks_sent"] is True
+        assert d["parity_check"]["bit_exact"] is True
 
 
 def _two_ranks(*extra, env_extra=None, expect_ok=True):
@@ -65,7 +82,7 @@ def test_two_ranks_on_one_gpu_line(collective):
     d, _ = _two_ranks("--gather", collective)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     mg = d["multi_gpu"]
-    assert mg["rccl_ranks_seen"] == 2 and len(mg["per_rank_ms_per_step"]) == 2 and mg["gather_ms"] is not None
+    assert mg["ranks_seen_by_all_reduce"] == 2 and mg["backend"] == "gloo" and len(mg["per_rank_ms_per_step"]) == 2 and mg["gather_ms"] is not None
     assert mg["gather_overlapped"] is True and mg["collective"] == collective and mg["gathered_image_matches_what_the_ranks_sent"] is True
 
 

@@ -120,3 +120,21 @@ def test_refine_cli_writes_the_bake_file_set(tmp_path):
     rs.main(argv)                                          # default: overwrite, as the reference does
     assert os.stat(f0).st_mtime_ns != mt
     np.testing.assert_array_equal(exr.read_exr(f0), a)     # (and reproducibly: per-view seeds)
+    # what a marker must NOT survive (advisor, round 3): a re-bake of the view, a changed input file under an unchanged path
+    mt = os.stat(f0).st_mtime_ns
+    rs.main(argv + ["--resume"])
+    assert os.stat(f0).st_mtime_ns == mt                   # (markers of the run above are valid)
+    bs.main(["--scene", str(scene_dir), "--slf_path", sp, "--emitter_path", ep, "--output", out, "--dataset", "generic", "--cameras", str(tmp_path / "cams.json"),
+             "--spp_diffuse", "8", "--spps_specular", "4", "4", "4", "4", "4", "4", "--seed", "2", "--overwrite"])
+    assert not os.path.exists(os.path.join(out, "diffuse", "000.refined"))       # the bake took the marker with it
+    np.testing.assert_array_equal(exr.read_exr(f0), baked[f0])
+    rs.main(argv + ["--resume"])                           # ... so the re-baked view is refined again
+    np.testing.assert_array_equal(exr.read_exr(f0), a)
+    mt = os.stat(f0).st_mtime_ns
+    st = os.stat(ep)
+    os.utime(ep, ns=(st.st_atime_ns, st.st_mtime_ns + 10_000_000_000))          # the emitter file "changed" (same path, newer)
+    rs.main(argv + ["--resume"])
+    assert os.stat(f0).st_mtime_ns != mt
+    import json as _json
+    m = _json.load(open(os.path.join(out, "diffuse", "000.refined")))
+    assert len(m["files"]) == 13 and m["run_key"]

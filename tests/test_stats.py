@@ -38,7 +38,7 @@ def test_stats_invariants_and_variant_agreement(dev, room_setup, spp):
     for lobe, rough in ((0, None), (1, 0.02), (4, 0.608), (6, 1.0)):
         got = {}
         for variant in (L.BAKE_TILE_SORTED, L.BAKE_PIXEL_PER_WAVE):
-            st = torch.zeros(16, device=dev, dtype=torch.int64)
+            st = torch.zeros(20, device=dev, dtype=torch.int64)
             if rough is None:
                 a = (bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, seed=1, stream_id=0, stats=st, variant=variant),)
                 b = (bs.bake_diffuse(s["sc"], s["em"], pos, nrm, spp, seed=1, stream_id=0, variant=variant),)

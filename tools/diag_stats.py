@@ -20,7 +20,7 @@ STAT_NAMES = ["rays", "node_visits", "tri_tests", "wave_node_iters", "wave_leaf_
 
 
 def check_invariants(st, expected_rays):
-    """Invariants of one instrumented launch (st: int64[16]).  Returns a list of violated ones."""
+    """Invariants of one instrumented launch (st: int64[20]).  Returns a list of violated ones."""
     bad = []
     rays, nodes, tris, nit, lit, g8, g12, g16 = [int(x) for x in st[:8]]
     if rays != expected_rays: bad.append(f"rays {rays} != P*spp {expected_rays}")
@@ -64,7 +64,7 @@ def main():
     ok = True
     for l in [int(x) for x in args.lobes.split(",")]:
         for variant in (L.BAKE_TILE_SORTED, L.BAKE_PIXEL_PER_WAVE):
-            stats = torch.zeros(16, device=dev, dtype=torch.int64)
+            stats = torch.zeros(20, device=dev, dtype=torch.int64)
             if l == 0:
                 a = bs.bake_diffuse(scene, emitter, g["position"][sel], g["normal"][sel], spp, seed=0, stream_id=0, pix_id=g["pix_id"][sel], stats=stats, variant=variant)
                 b = bs.bake_diffuse(scene, emitter, g["position"][sel], g["normal"][sel], spp, seed=0, stream_id=0, pix_id=g["pix_id"][sel], variant=variant)

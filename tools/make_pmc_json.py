@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Assemble profiles/pmc_r2.json -- what bench.py's roofline reads -- from
+"""Assemble profiles/pmc_r4.json -- what bench.py's roofline reads -- from
   * gpurun_out/pmc_<tag>/pmc.json   per-launch counter means + kernel duration + source hash (tools/pmc_profile.sh on the GPU box)
   * gpurun_out/pmc_<tag>/trace.log  bench.py's own JSON line of the traced run (rays per launch)
   * profiles/r2_microbench.jsonl    tools/microbench results: TA cycles per wave-load as a function of the distinct lines it touches
@@ -9,7 +9,7 @@ import json, os, subprocess, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "pmc_r2.json")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "pmc_r4.json")
 pj = json.load(open(os.path.join(src, "pmc.json")))
 line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
 bj = json.loads(line)

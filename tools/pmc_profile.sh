@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes for the bake kernels (run on the GPU box via gpurun).  One kernel-trace pass (durations), then one pass per counter
 # group -- counters are collected in their own runs, never mixed with tracing.  Per-dispatch means land in gpurun_out/pmc_<tag>/summary.txt
-# and, with the source hash of the kernels they were taken on, in gpurun_out/pmc_<tag>/pmc.json (bench.py reads profiles/pmc_r2.json).
+# and, with the source hash of the kernels they were taken on, in gpurun_out/pmc_<tag>/pmc.json (bench.py reads profiles/pmc_r4.json).
 # usage: [IRIS_HIP_LIB=...] tools/pmc_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true

@@ -1,6 +1,6 @@
 """Summarise the rocprofv3 output of tools/pmc_profile.sh: mean counter value per kernel name (per dispatch) as text on stdout, and
 <dir>/pmc.json = per-launch means of the dominant kernel + its mean duration from the kernel-trace pass + the source hash of the
-kernels (iris_amd._lib.source_hash) -- the file bench.py's roofline reads (committed as profiles/pmc_r2.json)."""
+kernels (iris_amd._lib.source_hash) -- the file bench.py's roofline reads (committed as profiles/pmc_r4.json)."""
 import collections
 import csv
 import glob
