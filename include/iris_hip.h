@@ -37,6 +37,7 @@ typedef void *iris_stream_t; /* hipStream_t */
 typedef struct iris_scene iris_scene;     /* triangle mesh + BVH            (mitsuba scene, bake_shading.py:55-61) */
 typedef struct iris_slf iris_slf;         /* VoxelSLF                       (model/slf.py:16-39)                   */
 typedef struct iris_emitter iris_emitter; /* SLFEmitter's emitter tables    (model/emitter.py:134-173)             */
+typedef struct iris_ngp iris_ngp;         /* NGPBRDF's hash grid + MLP      (model/brdf.py:213-260)                */
 
 enum { IRIS_OK = 0, IRIS_ERR_ARG = 1, IRIS_ERR_HIP = 2, IRIS_ERR_BUILD = 3 };
 
@@ -252,6 +253,18 @@ IRIS_API uint64_t iris_denoise_workspace_bytes(int H, int W);
 IRIS_API int iris_denoise(const float *normal, const float *position, const uint8_t *valid, int H, int W, int n_maps, const float *const *in,
                  float *const *out, int iterations, float sigma_l, float sigma_n, float sigma_p, void *workspace, uint64_t workspace_bytes,
                  iris_stream_t);
+
+/* ---- the material network of the refine / emitter-training stages, inference only ----------------------- */
+/* NGPBRDF (model/brdf.py:213-260; loaded and frozen at refine_shading.py:83-92, train_emitter.py:67-77): tiny-cuda-nn
+ * NetworkWithInputEncoding(3, 5, HashGrid{n_levels 32, 2 features, log2_hashmap_size 19, base 16, per_level_scale 1.3},
+ * FullyFusedMLP{64 neurons, 2 hidden layers, ReLU}) + sigmoid.  params: HOST float32[n_params] = the `mlp.params` tensor of the reference's
+ * state dict ([MLP weights 64x64, 64x64, 16x64 row-major | grid tables level by level, 2 features per entry]); n_params must equal
+ * iris_ngp_n_params().  tiny-cuda-nn is third party: the published algorithm is implemented, parity unpinned (oracle/ngp_torch.py). */
+IRIS_API int64_t iris_ngp_n_params(void);
+IRIS_API int iris_ngp_create(const float *params, int64_t n_params, double voxel_min, double voxel_max, int device, iris_ngp **out);
+/* forward(position): position (N,3) f32 world space -> albedo (N,3), roughness (N) in [0.02,1], metallic (N), all f32 device pointers */
+IRIS_API int iris_ngp_forward(const iris_ngp *, const float *position, int64_t N, float *albedo, float *roughness, float *metallic, iris_stream_t);
+IRIS_API void iris_ngp_destroy(iris_ngp *);
 
 /* ---- misc --------------------------------------------------------------------------------------------- */
 /* Philox uniforms exactly as the bake kernels draw them (for tests): u2[i] = U(seed, idx0+i, stream_id). */

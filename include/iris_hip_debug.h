@@ -46,6 +46,9 @@ IRIS_API int iris_debug_bake_specular(const iris_scene *, const iris_emitter *, 
  *   "pt_tile_min": smallest batch the path-tracing stages route through the tile-sorted kernel
  * NOT thread-safe: plain process-wide globals that iris_scene_create / the launches read.  Set them before creating handles, from one thread. */
 IRIS_API int iris_debug_set(const char *key, long long value);
+/* NGPBRDF: the hash-grid encoding alone (tests compare it bit for bit with the restatement; the perceptron behind it only to a tolerance):
+ * features of N <= 2^20 positions as the kernels hand them over, feat[level * N + i] = the level's two half features of point i (one uint32). */
+IRIS_API int iris_debug_ngp_encode(const iris_ngp *, const float *position, int64_t N, uint32_t *feat, iris_stream_t);
 /* The compiler flags this library was built with (iris_amd/csrc/Makefile embeds them): part of the stamp that ties a counter profile to a build. */
 IRIS_API const char *iris_debug_build_flags(void);
 

@@ -59,6 +59,11 @@ PROTOTYPES = {
     "iris_angle2xyz": [_P, _P, _I64, _P, _P],
     "iris_ggx_terms": [_I32, _P, _P, _P, _I64, _P, _P, _P],
     "iris_philox_u2": [_U64, _U64, _U32, _I64, _P, _P],
+    "iris_ngp_n_params": [],
+    "iris_ngp_create": [_P, _I64, C.c_double, C.c_double, C.c_int, _P],
+    "iris_ngp_forward": [_P, _P, _I64, _P, _P, _P, _P],
+    "iris_ngp_destroy": [_P],
+    "iris_debug_ngp_encode": [_P, _P, _I64, _P, _P],
     "iris_sample_emitter": [_P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "iris_eval_brdf": [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
     "iris_sample_brdf": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
@@ -85,7 +90,7 @@ PROTOTYPES = {
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_ngp_n_params": C.c_int64, "iris_ngp_destroy": None, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
 
 _lib = None
 

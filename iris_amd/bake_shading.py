@@ -312,14 +312,14 @@ class MapWriter:
             tmp = path + ".part"
             exr.write_exr_blocks(tmp, H, W, self.compression, hfull[j], htail[j], pool=chunks)
             os.replace(tmp, path)
-        futs = [self.pool.submit(write, f, j) for j, f in enumerate(files)]
+        writes = [self.pool.submit(write, f, j) for j, f in enumerate(files)]
+        self.busy[i] = list(writes)
         if on_written is not None:
-            def finish():
-                for f in futs:
+            def finish(writes=tuple(writes)):               # (bound now: the list below also holds this task's own future)
+                for f in writes:
                     f.result()                              # (a failed write re-raises here and the marker is not written)
                 on_written()
-            futs = futs + [self.pool.submit(finish)]        # queued behind the writes it waits for
-        self.busy[i] = futs
+            self.busy[i].append(self.pool.submit(finish))   # queued behind the writes it waits for
 
     def close(self):
         for fs in self.busy:

@@ -18,6 +18,7 @@
 #include "iris_pt.h"
 #include "iris_cache.h"
 #include "iris_denoise.h"
+#include "iris_ngp.h"
 
 using namespace iris;
 
@@ -330,6 +331,105 @@ extern "C" IRIS_API void iris_slf_destroy(iris_slf* s) {
     if (!s) return;
     (void)hipFree(s->d_inds); (void)hipFree(s->d_rad);
     delete s;
+}
+
+// ======================================================================================================
+// NGPBRDF (model/brdf.py:213-260): hash-grid encoding + MLP, inference
+// ======================================================================================================
+struct iris_ngp {
+    int device = 0;
+    NgpLevels lv{};
+    void* d_grid = nullptr;     // half2 entries
+    void* d_w = nullptr;        // kNgpMlpParams halves
+    void* d_feat = nullptr;     // [32 levels][kChunk] half2: the encoded features of one chunk of points
+    float vmin = 0.f, den = 1.f;
+    uint64_t n_entries = 0;
+};
+constexpr int kNgpChunk = 1 << 20;       // points per encode / MLP launch pair: 128 MiB of features
+static uint64_t ngp_levels(NgpLevels& lv) {
+    // tiny-cuda-nn GridEncoding: scale = exp2(level * log2(per_level_scale)) * base - 1, resolution = ceil(scale) + 1, entries = min(round_up(res^3, 8), 2^19)
+    // (the library evaluates this in float with the device's fast exp2f, whose last bits are not reproducible; here every transcendental is taken in double
+    //  and rounded to float once, so that any host libm gives the same table: log2(1.3f) -> float, level * that in float, exp2 -> float, * 16 - 1 in float)
+    const float log2_scale = (float)log2((double)1.3f);
+    uint64_t off = 0;
+    for (int l = 0; l < kNgpLevels; ++l) {
+        const float scale = (float)exp2((double)((float)l * log2_scale)) * 16.f - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        uint64_t n = (uint64_t)res * res * res;
+        n = std::min<uint64_t>(n, 0xFFFFFFFFull / 2);
+        n = (n + 7) / 8 * 8;
+        n = std::min<uint64_t>(n, 1ull << 19);
+        lv.scale[l] = scale; lv.res[l] = res; lv.size[l] = (uint32_t)n; lv.offset[l] = (uint32_t)off;
+        off += n;
+    }
+    return off;
+}
+static uint16_t f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }     // round to nearest even, as torch's .half()
+extern "C" IRIS_API int64_t iris_ngp_n_params(void) {
+    NgpLevels lv;
+    return (int64_t)kNgpMlpParams + (int64_t)ngp_levels(lv) * 2;
+}
+extern "C" IRIS_API int iris_ngp_create(const float* params, int64_t n_params, double voxel_min, double voxel_max, int device, iris_ngp** out) {
+    API_BEGIN
+    if (!out || !params) return fail(IRIS_ERR_ARG, "iris_ngp_create: bad arguments");
+    iris_ngp* g = new iris_ngp();
+    g->device = device;
+    g->n_entries = ngp_levels(g->lv);
+    if (n_params != (int64_t)kNgpMlpParams + (int64_t)g->n_entries * 2) {
+        delete g;
+        return fail(IRIS_ERR_ARG, "iris_ngp_create: mlp.params has " + std::to_string(n_params) + " entries, the NGPBRDF configuration has " + std::to_string(iris_ngp_n_params()));
+    }
+    HIP_TRY(hipSetDevice(device));
+    std::vector<uint16_t> h((size_t)n_params);
+    for (int64_t i = 0; i < n_params; ++i) h[(size_t)i] = f32_to_f16_bits(params[i]);
+    auto cleanup = [&](const char* msg) { (void)hipFree(g->d_grid); (void)hipFree(g->d_w); (void)hipFree(g->d_feat); delete g; return fail(IRIS_ERR_HIP, msg); };
+    if (hipMalloc(&g->d_w, (size_t)kNgpMlpParams * 2) != hipSuccess || hipMalloc(&g->d_grid, (size_t)g->n_entries * 4) != hipSuccess ||
+        hipMalloc(&g->d_feat, (size_t)kNgpLevels * kNgpChunk * 4) != hipSuccess)
+        return cleanup("iris_ngp_create: out of device memory");
+    if (hipMemcpy(g->d_w, h.data(), (size_t)kNgpMlpParams * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->d_grid, h.data() + kNgpMlpParams, (size_t)g->n_entries * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup("iris_ngp_create: upload failed");
+    g->vmin = (float)voxel_min;
+    g->den = (float)(voxel_max - voxel_min);           // (the difference of the two python floats, taken in double, enters the float32 tensor arithmetic as one scalar)
+    *out = g;
+    return IRIS_OK;
+    API_END
+}
+extern "C" IRIS_API int iris_ngp_forward(const iris_ngp* g, const float* position, int64_t N, float* albedo, float* roughness, float* metallic, iris_stream_t stream) {
+    API_BEGIN
+    if (!g || N < 0 || (N > 0 && (!position || !albedo || !roughness || !metallic))) return fail(IRIS_ERR_ARG, "iris_ngp_forward: bad arguments");
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t st = (hipStream_t)stream;
+    NgpArgs a{};
+    a.lv = g->lv; a.grid = (const uint32_t*)g->d_grid; a.w = (const _Float16*)g->d_w; a.pos = position; a.feat = (uint32_t*)g->d_feat;
+    a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.n_chunk = kNgpChunk; a.vmin = g->vmin; a.den = g->den;
+    for (int64_t n0 = 0; n0 < N; n0 += kNgpChunk) {          // (stream-ordered: the feature planes of a chunk are consumed before the next chunk's encode overwrites them)
+        a.n0 = n0; a.n = (int)std::min<int64_t>(kNgpChunk, N - n0);
+        hipLaunchKernelGGL(ngp_encode_kernel, dim3((a.n + 255) / 256, kNgpLevels), dim3(256), 0, st, a);
+        const int tiles = (a.n + 31) / 32;
+        hipLaunchKernelGGL(ngp_mlp_kernel, dim3(std::min(std::max((tiles + 3) / 4, 1), 2048)), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+    API_END
+}
+extern "C" IRIS_API int iris_debug_ngp_encode(const iris_ngp* g, const float* position, int64_t N, uint32_t* feat, iris_stream_t stream) {
+    API_BEGIN
+    if (!g || N < 0 || N > kNgpChunk || (N > 0 && (!position || !feat))) return fail(IRIS_ERR_ARG, "iris_debug_ngp_encode: bad arguments");
+    if (N == 0) return IRIS_OK;
+    HIP_TRY(hipSetDevice(g->device));
+    NgpArgs a{};
+    a.lv = g->lv; a.grid = (const uint32_t*)g->d_grid; a.w = (const _Float16*)g->d_w; a.pos = position; a.feat = feat;
+    a.n_chunk = (int)N; a.vmin = g->vmin; a.den = g->den; a.n0 = 0; a.n = (int)N;
+    hipLaunchKernelGGL(ngp_encode_kernel, dim3((a.n + 255) / 256, kNgpLevels), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+    API_END
+}
+extern "C" IRIS_API void iris_ngp_destroy(iris_ngp* g) {
+    if (!g) return;
+    (void)hipFree(g->d_grid); (void)hipFree(g->d_w); (void)hipFree(g->d_feat);
+    delete g;
 }
 
 extern "C" IRIS_API int iris_emitter_create(const uint8_t* is_emitter, int64_t nf, const float* radiance, int64_t n_rad, const float* area,

@@ -134,3 +134,75 @@ class BaseBRDF(nn.Module):
             L.check(L.lib().iris_sample_brdf(L.ptr(sample1), L.ptr(sample2), L.ptr(wo), L.ptr(normal), L.ptr(albedo), L.ptr(rough), L.ptr(metal), B,
                                              L.ptr(wi), L.ptr(pdf), L.ptr(w), L.stream()))
         return wi, pdf, w
+
+
+class _TcnnParams(nn.Module):
+    """Stands where the reference has `self.mlp = tcnn.NetworkWithInputEncoding(...)`: it owns the ONE flat float32 parameter tensor tiny-cuda-nn's
+    torch module registers as `params`, so the state-dict key is `mlp.params` as in the reference's checkpoints (refine_shading.py:84-89 strips the
+    'material.' prefix and calls load_state_dict)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.params = nn.Parameter(torch.zeros(n, dtype=torch.float32), requires_grad=False)
+
+
+class NGPBRDF(BaseBRDF):
+    """Hash-grid material network, INFERENCE ONLY (model/brdf.py:213-260; the reference loads it from a checkpoint and freezes it in refine_shading.py:83-92
+    and train_emitter.py:67-77): HashGrid{32 levels x 2 features, 2^19 entries, base 16, x1.3} -> FullyFusedMLP{64 x 2, ReLU} -> sigmoid, as two HIP
+    kernels (level-major gathers; the perceptron on the matrix cores, iris_amd/csrc/iris_ngp.h).  tiny-cuda-nn is third party and CUDA only: its published
+    algorithm is implemented, parity unpinned (oracle/ngp_torch.py).  No backward pass: training the material network is train_brdf_crf's job (out of scope)."""
+
+    def __init__(self, voxel_min, voxel_max):
+        super().__init__()
+        self.voxel_min, self.voxel_max = float(voxel_min), float(voxel_max)
+        self.mlp = _TcnnParams(int(L.lib().iris_ngp_n_params()))
+        self._h, self._h_key = None, None
+
+    def _handle(self, device):
+        import ctypes as C
+        p = self.mlp.params
+        key = (str(device), p.data_ptr(), p._version)
+        if self._h is None or self._h_key != key:
+            self._free()
+            host = p.detach().to("cpu", torch.float32).contiguous()
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            h = C.c_void_p()
+            L.check(L.lib().iris_ngp_create(C.c_void_p(host.data_ptr()), host.numel(), self.voxel_min, self.voxel_max, idx, C.byref(h)))
+            self._h, self._h_key = h, key
+        return self._h
+
+    def _free(self):
+        h = self.__dict__.get("_h")
+        if h is not None:
+            self.__dict__["_h"] = None              # (not through nn.Module.__setattr__: at interpreter shutdown its helpers may be gone)
+            try:
+                L.lib().iris_ngp_destroy(h)
+            except Exception:     # noqa  (interpreter shutdown)
+                pass
+
+    def __del__(self):
+        self._free()
+
+    def forward(self, position):
+        """position Bx3 (world space) -> {'albedo': Bx3, 'roughness': Bx1 in [0.02, 1], 'metallic': Bx1}  (model/brdf.py:243-260)"""
+        L.no_autograd("NGPBRDF.forward", position)
+        position = L.require_gpu(position, torch.float32, "position")
+        shape = position.shape[:-1]
+        pos = position.reshape(-1, 3)
+        N, dev = pos.shape[0], pos.device
+        albedo = torch.empty(N, 3, device=dev); rough = torch.empty(N, device=dev); metal = torch.empty(N, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().iris_ngp_forward(self._handle(dev), L.ptr(pos), N, L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.stream()))
+        return {"albedo": albedo.reshape(*shape, 3), "roughness": rough.reshape(*shape, 1), "metallic": metal.reshape(*shape, 1)}
+
+
+def load_ngpbrdf(voxel_min, voxel_max, ckpt):
+    """The reference's loading sequence (refine_shading.py:83-92): NGPBRDF(voxel_min, voxel_max), the checkpoint's 'state_dict' entries under 'material.'
+    with the prefix stripped, load_state_dict, frozen."""
+    net = NGPBRDF(voxel_min, voxel_max)
+    state = torch.load(ckpt, map_location="cpu")["state_dict"]
+    weight = {k.replace("material.", ""): v for k, v in state.items() if "material." in k}
+    net.load_state_dict(weight)
+    for p in net.parameters():
+        p.requires_grad = False
+    return net

@@ -3,10 +3,11 @@ through the current material estimate -- per view a deterministic first hit, the
 and `path_tracing_det_spec` for the six roughness levels (spp 64), denoised and written to the same 13 EXR files the bake wrote.
 
 The integrators are the HIP stages of `iris_amd.utils.path_tracing` (parity: tests/test_refine.py against the reference's goldens).  The
-material network is the reference's `NGPBRDF` -- a tiny-cuda-nn hash grid, third party and absent here -- so the driver takes ANY
-`material_net(position) -> {'albedo','roughness','metallic'}` module: `refine_view(...)` as a library call, `--material pkg.module:factory`
-on the command line (the factory is called with the (voxel_min, voxel_max) pair `NGPBRDF` is constructed from, refine_shading.py:83-84, and
-`--ckpt` is handed to it when given).
+material network is the reference's `NGPBRDF` (model/brdf.py:213-260, a tiny-cuda-nn hash grid + MLP): `iris_amd.model.brdf.NGPBRDF` runs its
+inference as HIP kernels (hash-grid gathers + the perceptron on the matrix cores) and is loaded from `--ckpt` exactly as the reference loads it
+(refine_shading.py:83-92).  The driver also takes ANY `material_net(position) -> {'albedo','roughness','metallic'}` module: `refine_view(...)` as
+a library call, `--material pkg.module:factory` on the command line (the factory is called with the (voxel_min, voxel_max) pair `NGPBRDF` is
+constructed from, and `--ckpt` is handed to it when given).
 """
 import importlib
 import math
@@ -83,6 +84,14 @@ def refine_view(scene, emitter, material_net, xs, ds, spp_diffuse=SPP_DIFFUSE, s
 
 
 def _load_material(spec, slf_path, ckpt):
+    """The material network: by default the reference's own -- NGPBRDF(mask['voxel_min'], mask['voxel_max']) with the checkpoint's 'material.' weights
+    (refine_shading.py:82-92) --, or, with --material pkg.module:factory, any callable position -> {'albedo','roughness','metallic'}."""
+    if not spec:
+        from .model.brdf import load_ngpbrdf
+        if not ckpt:
+            raise L.IrisError("refine_shading: --ckpt (the checkpoint holding the NGPBRDF weights, refine_shading.py:36,84) or --material pkg.module:factory is required")
+        mask = torch.load(slf_path, map_location="cpu")
+        return load_ngpbrdf(mask["voxel_min"], mask["voxel_max"], ckpt)
     mod, _, attr = spec.partition(":")
     factory = getattr(importlib.import_module(mod), attr or "material")
     mask = torch.load(slf_path, map_location="cpu")
@@ -94,7 +103,7 @@ def _load_material(spec, slf_path, ckpt):
 
 def main(argv=None):
     """python -m iris_amd.refine_shading --scene S --slf_path vslf.npz --emitter_path emitter.pth --output OUT --dataset synthetic|real|generic
-       --material pkg.module:factory [--ckpt last.ckpt]          (the reference's flags; --material replaces the hard-wired NGPBRDF)"""
+       --ckpt last.ckpt [--material pkg.module:factory]          (the reference's flags; --material replaces the NGPBRDF the reference hard-wires)"""
     import argparse
     from .model.emitter import SLFEmitter
     from .utils import cameras, exr
@@ -110,7 +119,8 @@ def main(argv=None):
     parser.add_argument("--ldr_img_dir", type=str, default=None)
     parser.add_argument("--res_scale", type=float, default=1.0)
     # additions (defaults reproduce the reference)
-    parser.add_argument("--material", type=str, required=True, help="pkg.module:factory returning material_net(position) -> {'albedo','roughness','metallic'}")
+    parser.add_argument("--material", type=str, default=None, help="pkg.module:factory returning material_net(position) -> {'albedo','roughness','metallic'} "
+                        "(default: the reference's NGPBRDF, loaded from --ckpt)")
     parser.add_argument("--cameras", type=str, default=None, help="generic camera JSON (required for scannetpp: COLMAP I/O is out of scope)")
     parser.add_argument("--img_hw", type=int, nargs=2, default=None)
     parser.add_argument("--spp_diffuse", type=int, default=SPP_DIFFUSE)
