@@ -135,6 +135,9 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const Ray
                                   uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
 #define IRIS_HITKEY(tn, tf) ((tn) <= (tf) ? (tn) : INFINITY)
 
+// (Loop control: `__popcll(m) >= k` stays a 64-bit comparison, which the scalar ALU cannot do, so hipcc runs it on the vector ALU -- v_cmp_lt_u64 on scalar
+//  operands, in front of every node and leaf step.  Counting the two mask halves with 32-bit scalar instructions instead was measured SLOWER, -0.8 %: the longer
+//  scalar dependency chain in front of the step costs more than the vector issue slot, EXPERIMENTS.md round 4.)
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
     return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
@@ -276,6 +279,61 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
     }
 }
+// A node visit made TOGETHER (round 4).  Instrumented launches say that in 36 % of the node steps at least 32 of the lanes at a node sit at the SAME node
+// of the same octant table -- rays of one direction bin, refilled together, walk the top of the tree together: 48 % of all node visits, 51 lanes at a time.
+// When at least IRIS_SCALAR_TOP lanes share the node (byte offset off0, wave-uniform), its 16 words come through the SCALAR cache (one s_load_dwordx16), the
+// plane bytes are isolated on the scalar ALU (a byte zero-extended in a scalar register IS the f16 subnormal v_fma_mix_f32 reads) and the slab tests take
+// them as scalar operands: no vector loads, no address arithmetic, no v_perm_b32 for that visit (50 instead of 63 vector instructions in front of the
+// push logic).  Same arithmetic, same bits; the few lanes at other nodes sit the step out.  Measured +2.5 % at a threshold of 44 lanes (32: +0.7 %,
+// 38-47: +1.0 ... +1.2 % before the detection reused the loop head's ballot, 50: -0.4 %, 56: -2.2 %: below ~36 lanes the lanes sitting out cost more than
+// the shared visit saves, above ~48 the test itself -- two vector instructions in front of EVERY node step -- is paid too often for nothing).  0 = off.
+#ifndef IRIS_SCALAR_TOP
+#define IRIS_SCALAR_TOP 44
+#endif
+#if IRIS_SCALAR_TOP
+typedef __attribute__((address_space(4))) const uint32_t cst_u32;
+template <class STACK>
+__device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r, STACK& st, uint32_t off0) {
+    // (inline asm: through a pointer hipcc proves the table global, falls back to four vector loads of the uniform address and turns the byte pairing
+    //  below back into v_perm_b32)
+    typedef uint32_t iris_u16v __attribute__((ext_vector_type(16)));
+    iris_u16v w;
+    const uint64_t base = reinterpret_cast<uint64_t>(sc.nodes);
+    const uint32_t off_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)off0);    // (inside `if (off == off0)` hipcc substitutes the per-lane value for the uniform one)
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(base), "s"(off_s) : "memory");
+    const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
+    uint32_t r0 = w[12], r1 = w[13], r2 = w[14], r3 = w[15];
+    const float ax = __uint_as_float(w[3]) * ix, ay = __uint_as_float(w[4]) * iy, az = __uint_as_float(w[5]) * iz;
+    const float bx = fmaf(__uint_as_float(w[0]), ix, nx), by = fmaf(__uint_as_float(w[1]), iy, ny), bz = fmaf(__uint_as_float(w[2]), iz, nz);
+    const uint32_t nxq = w[6], nyq = w[7], nzq = w[8], fxq = w[9], fyq = w[10], fzq = w[11];
+    typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
+#define IRIS_PAIR(NQ, FQ, C) __builtin_bit_cast(iris_h2, (uint32_t)((((NQ) >> (8 * (C))) & 0xffu) | ((((FQ) >> (8 * (C))) & 0xffu) << 16)))
+#define IRIS_SLABS(D, C)                                                                                                          \
+    {                                                                                                                             \
+        const iris_h2 hx = IRIS_PAIR(nxq, fxq, C), hy = IRIS_PAIR(nyq, fyq, C), hz = IRIS_PAIR(nzq, fzq, C);                       \
+        float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
+        float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
+        D = tf - tn;                                                                                                              \
+    }
+    float d0, d1, d2, d3;
+    IRIS_SLABS(d0, 0) IRIS_SLABS(d1, 1) IRIS_SLABS(d2, 2) IRIS_SLABS(d3, 3)
+#undef IRIS_SLABS
+#undef IRIS_PAIR
+    const int32_t b0 = __float_as_int(d0), b1 = __float_as_int(d1), b2 = __float_as_int(d2), b3 = __float_as_int(d3);
+    const int32_t n01 = b0 & b1, n012 = n01 & b2;
+    if ((n012 & b3) >= 0) {
+        uint32_t c = b2 >= 0 ? r2 : r3;
+        c = b1 >= 0 ? r1 : c;
+        r.cur = b0 >= 0 ? r0 : c;
+        if ((b3 | n012) >= 0) st.push(r3);
+        if ((b2 | n01) >= 0) st.push(r2);
+        if ((b1 | b0) >= 0) st.push(r1);
+    } else {
+        r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+    }
+}
+#endif
+
 // One triangle of the current leaf.
 __device__ __forceinline__ RayXf leaf_phase_xform(const RayState& r) {
     RayXf x;
@@ -383,10 +441,21 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
         // ---------------- node phase
         for (;;) {
             const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
-            const int n_node = __popcll(__ballot(at_node));
+            const unsigned long long m_node = __ballot(at_node);
+            const int n_node = __popcll(m_node);
             if (n_node == 0) break;
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
+#if IRIS_SCALAR_TOP
+            if (!COUNT && LAYOUT == kLayoutQ8) {
+                const uint32_t off = (r.cur << 6) + r.oct_base;                 // (meaningless in the lanes that are not at a node: masked out below)
+                const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __ffsll((long long)m_node) - 1);
+                if ((int)__popcll(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
+                    if (at_node && off == off0) node_step_shared(sc, r, st, off0);
+                    continue;
+                }
+            }
+#endif
             if (at_node) {
                 if (COUNT) { ts->nodes++; ts->count_top(r.cur); ts->count_shared(r.cur, r.oct_base); if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
                 node_step<LAYOUT>(sc, r, st);
