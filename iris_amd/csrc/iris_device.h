@@ -21,6 +21,10 @@ __device__ __forceinline__ float x_dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(
 
 // ---- torch-order helpers (sum over the last dim in index order, no fma) ----
 __device__ __forceinline__ float t_dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// (Three divisions by one denominator.  hipcc expands each into v_div_scale x 2, v_rcp_f32, two Newton steps, q = a r, two residual corrections, v_div_fmas,
+//  v_div_fixup; for operands inside the normal range the scale / fixup steps are the identity, so the reciprocal's refinement can be SHARED by the three
+//  numerators and the result stays bit-identical -- 18 instead of 33 instructions per normalisation, verified bit for bit at BASELINE configs[1] size.  Measured
+//  -1.0 % on the view kernel (EXPERIMENTS.md round 4): fewer instructions, more live registers through the sampling code.  Not kept.)
 // NF.normalize(v, dim=-1) = v / max(||v||, 1e-12)
 __device__ __forceinline__ f3 t_normalize(f3 a) {
     float n = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);

@@ -26,7 +26,8 @@ namespace iris {
 // whose 64 consecutive rays of the sorted list come from one octant touches fewer lines per load.  Inside the octant the L1-normalised |d| lies in a
 // triangle (a + b <= 1), mapped to the unit square by (a, b / (1 - a)) and cut into 8 x 4 cells, columns walked alternately up and down.
 // Measured against the 16 x 16 Morton-ordered octahedral map of rounds 1-3 (whose cells straddle octants along the axes and diagonals): +2.0 %;
-// Morton order inside the octant, 4 x 8 cells, the triangle cut directly, Gray-code order of the octants: -0.1 ... -0.8 % against this.
+// Morton order inside the octant, 4 x 8 cells, the triangle cut directly, Gray-code order of the octants: -0.1 ... -0.8 % against this; 4 x 4 cells
+// (128 bins; round 4, with the shared node visits of iris_trace.h, which like waves of one cell): -0.4 %.
 // (1-ulp reciprocals are plenty for a bin: results do not depend on the binning.)
 __device__ __forceinline__ uint32_t dir_bin(f3 d) {
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
