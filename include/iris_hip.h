@@ -262,7 +262,9 @@ IRIS_API int iris_denoise(const float *normal, const float *position, const uint
  * iris_ngp_n_params().  tiny-cuda-nn is third party: the published algorithm is implemented, parity unpinned (oracle/ngp_torch.py). */
 IRIS_API int64_t iris_ngp_n_params(void);
 IRIS_API int iris_ngp_create(const float *params, int64_t n_params, double voxel_min, double voxel_max, int device, iris_ngp **out);
-/* forward(position): position (N,3) f32 world space -> albedo (N,3), roughness (N) in [0.02,1], metallic (N), all f32 device pointers */
+/* forward(position): position (N,3) f32 world space -> albedo (N,3), roughness (N) in [0.02,1], metallic (N), all f32 device pointers.
+ * The handle owns the feature buffer the two kernels of a call exchange (2^20 points x 128 B): calls on ONE handle must be ordered on one stream
+ * (or by events); different handles are independent. */
 IRIS_API int iris_ngp_forward(const iris_ngp *, const float *position, int64_t N, float *albedo, float *roughness, float *metallic, iris_stream_t);
 IRIS_API void iris_ngp_destroy(iris_ngp *);
 

@@ -581,14 +581,29 @@ def test_view_kernel_many_tiles_per_workgroup(dev, room_setup):
     assert torch.equal(res[2][0], a) and torch.equal(res[2][1], b)         # variant 1 = pixel-per-wave kernel: no result slots at all
 
 
-def test_full_size_1080p_determinism_and_kernel_agreement(dev, room_setup):
-    """BASELINE.json's headline size (1920x1080 x SPP 128; two lobes here): the dynamically scheduled view kernel is bit-reproducible run to
-    run, equals the per-lobe tile kernel, and every row equals the bake of a small pixel subset (shard invariance) -- properties that
-    do not need the oracle at a size it could not finish."""
+@pytest.fixture(scope="module")
+def bench_scene_setup(dev, oracle_mod):
+    """bench.py's OWN workload (BASELINE configs[2]: room seed 1, 1.0 M triangles, H = 256 SLF), built by bench.build_workload, with its oracle twin"""
+    import argparse
+    import bench
+    a = argparse.Namespace(scene_seed=1, tris=1_000_000, slf_res=256, layout=0, long_walls=False)
+    room, slf_np, emi_np, scene, emitter = bench.build_workload(a, dev)
+    osc = oracle_mod.Scene(room["vertices"], room["faces"])
+    oslf = oracle_mod.VoxelSLF(slf_np["inds"], slf_np["radiance"], slf_np["voxel_min"], slf_np["voxel_max"])
+    oem = oracle_mod.SLFEmitter(emi_np["is_emitter"], emi_np["emitter_radiance"], emi_np["emitter_area"], oslf)
+    return {"sc": scene, "em": emitter, "osc": osc, "oem": oem, "room": room}
+
+
+@pytest.mark.parametrize("which", ["room_0.2M", "bench_scene_1.0M"])
+def test_full_size_1080p_determinism_and_kernel_agreement(dev, oracle_mod, room_setup, bench_scene_setup, which):
+    """BASELINE.json's headline size (1920x1080 x SPP 128; two lobes here), on the 0.2 M-triangle room and on THE SCENE bench.py TIMES (1.0 M triangles):
+    the dynamically scheduled view kernel is bit-reproducible run to run, equals the per-lobe tile kernel, every row equals the bake of a small pixel
+    subset (shard invariance) -- properties that do not need the oracle at a size it could not finish -- and a 4096-pixel subsample of the full-size
+    maps equals the device-arithmetic oracle bit for bit (what bench.py's parity_check does on the driver-timed run)."""
     from tools import synth
     from iris_amd import bake_shading as bs
     from iris_amd.utils.dataset import real_ldr
-    s = room_setup
+    s = room_setup if which == "room_0.2M" else bench_scene_setup
     H, W, spp = 1080, 1920, 128
     K, c2w = synth.camera(H, W, 9)
     xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
@@ -605,6 +620,15 @@ def test_full_size_1080p_determinism_and_kernel_agreement(dev, room_setup):
     sub = bs.bake_diffuse(s["sc"], s["em"], g["position"][sel], g["normal"][sel], spp, seed=13, stream_id=0, pix_id=g["pix_id"][sel])
     assert torch.equal(sub, r1[0][sel])
     assert torch.isfinite(r1[0]).all() and float(r1[0].min()) >= 0.0
+    pick = torch.linspace(0, P - 1, 4096, device=dev).round().long().unique()
+    pos, nrm, wo = (N(g[k][pick]) for k in ("position", "normal", "wo"))
+    pid = N(g["pix_id"][pick]).astype(np.int32)
+    with oracle_mod.device_arithmetic():
+        (od,) = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, seed=13, stream=0, pix_id=pid)
+        o0, o1 = oracle_mod.bake(s["osc"], s["oem"], pos, nrm, spp, wo=wo, roughness=np.float32(1.0), seed=13, stream=6, pix_id=pid)
+    np.testing.assert_array_equal(N(r1[0][pick]), od)
+    np.testing.assert_array_equal(N(r1[1][0][pick]), o0)
+    np.testing.assert_array_equal(N(r1[1][1][pick]), o1)
 
 
 def test_view_kernel_equals_per_lobe_launches(dev, room_setup):
