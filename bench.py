@@ -541,7 +541,10 @@ def main():
         #  bound by the host thread that issues them -- on a box whose cgroup grants exactly as many CPUs as that team has threads)
         # ---- extras: BASELINE configs[4] (train_brdf_crf / train_emitter inner loop: differentiable one-bounce path tracer, SPP 32) on the same scene
         from tools import bench_pt_single
-        result.setdefault("extras", {})["cfg5_path_tracing_single"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2)
+        # (through the reference's material network -- NGPBRDF as HIP kernels, random parameters of its configuration -- and, for continuity with rounds 1-3,
+        #  through the closed-form stand-in those rounds used)
+        result.setdefault("extras", {})["cfg5_path_tracing_single"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="ngp")
+        result["extras"]["cfg5_path_tracing_single_stub_material"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="stub")
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----

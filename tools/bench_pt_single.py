@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE cfg 5: path_tracing_single forward + backward throughput (8192 rays x spp 32, 4 calls per step as the reference's
-training_step does with SPP=128, train_emitter.py:181-189) on the synthetic 1 M-triangle room, stub material.
+training_step does with SPP=128, train_emitter.py:181-189) on the synthetic 1 M-triangle room, through the reference's material network
+(NGPBRDF, random parameters; --material stub: the closed-form stand-in of rounds 1-3).
 Prints one JSON line (paths/s = camera paths traced, shaded and back-propagated per second)."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +19,19 @@ class GpuStub(torch.nn.Module):
                 "metallic": 0.5 + 0.5 * torch.sin(x[:, 2:3] * 2.3)}
 
 
-def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp=32, calls=4, graph=False):
-    """-> dict: Mpaths/s of `steps` training steps (each `calls` forward calls + one backward) on an existing bench workload"""
+def ngp_material(slf, dev, seed=0):
+    """the reference's material network (NGPBRDF, model/brdf.py:213-260: hash grid + MLP, HIP kernels) with RANDOM parameters of its configuration -- there
+    is no checkpoint on this machine (no network, no dataset): the architecture, the table sizes and the gather pattern are the real ones"""
+    from iris_amd.model.brdf import NGPBRDF
+    net = NGPBRDF(slf["voxel_min"], slf["voxel_max"])
+    g = torch.Generator().manual_seed(seed)
+    net.load_state_dict({"mlp.params": (torch.rand(net.mlp.params.numel(), generator=g) * 2 - 1) * 0.3})
+    return net
+
+
+def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp=32, calls=4, graph=False, material="ngp"):
+    """-> dict: Mpaths/s of `steps` training steps (each `calls` forward calls + one backward) on an existing bench workload.
+    material: "ngp" = NGPBRDF with random parameters (the reference's network), "stub" = the closed-form stand-in of rounds 1-3"""
     from iris_amd.model.emitter import SLFEmitterLearn
     from iris_amd.utils.path_tracing import path_tracing_single
     from iris_amd.utils.dataset import real_ldr
@@ -38,7 +50,7 @@ def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp
     g = torch.Generator(device="cpu").manual_seed(0)
     pick = torch.randint(0, H * W, (rays,), generator=g).to(dev)
     o, d, dx, dy = o[pick], d[pick], dx[pick], dy[pick]
-    mat = GpuStub()
+    mat = ngp_material(slf, dev) if material == "ngp" else GpuStub()
     target = torch.rand(rays, 3, device=dev)
 
     def step():
@@ -84,7 +96,7 @@ def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp
     paths = steps * calls * rays * spp
     return {"metric": "path_tracing_single fwd+bwd (BASELINE configs[4]: train_emitter.py:181-189)", "value": round(paths / dt / 1e6, 2), "unit": "Mpaths/s",
             "ms_per_step": round(dt / steps * 1e3, 2),
-            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "hip_graph": bool(graph), "triangles": int(room["faces"].shape[0]), "material": "closed-form stub (NGPBRDF is third party)"},
+            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "hip_graph": bool(graph), "triangles": int(room["faces"].shape[0]), "material": ("NGPBRDF (hash grid 32 x 2 x 2^19 + MLP 64 x 2 on the matrix cores), random parameters" if material == "ngp" else "closed-form stub")},
             "grad_nonzero_rows": int((em.radiance.grad.abs().sum(-1) > 0).sum())}
 
 
@@ -94,12 +106,13 @@ def main():
     ap.add_argument("--rays", type=int, default=8192); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--calls", type=int, default=4)
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--graph", action="store_true", help="capture the training step in a HIP graph (torch.cuda.CUDAGraph) and replay it")
+    ap.add_argument("--material", choices=["ngp", "stub"], default="ngp")
     args = ap.parse_args()
     import bench
     dev = torch.device("cuda:0")
     ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
     room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
-    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph)))
+    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph, material=args.material)))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Measurements for SURVEY.md 8(f) rows 1 and 2 on the bench scene (1.0 M-triangle room, stub material):
+"""Measurements for SURVEY.md 8(f) rows 1 and 2 on the bench scene (1.0 M-triangle room; material = the reference's NGPBRDF with random
+parameters, --material stub for the closed-form stand-in of rounds 1-3):
   f1  refine_shading's diffuse pass (refine_shading.py:99-131): path_tracing_det_diff, spp 128, indir_depth 5, the reference's batches
       of 10240 pixels (--batch-pixels; 288 GB allows far bigger ones) -> first-bounce paths per second
   f2  the pre-bake chain (slf_bake.py:69-145, extract_emitter_ldr.py:72-115): bake_slf + extract_emitters over V 1080p views
@@ -10,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 
 
-from tools.bench_pt_single import GpuStub          # closed-form stand-in for NGPBRDF, constants uploaded once
+from tools.bench_pt_single import GpuStub, ngp_material
 
 
 def main():
@@ -18,6 +19,7 @@ def main():
     ap.add_argument("--batch-pixels", type=int, default=10240); ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--spp", type=int, default=128); ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--views", type=int, default=4); ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--material", choices=["ngp", "stub"], default="ngp")
     args = ap.parse_args()
     import bench
     from iris_amd import slf_bake as sb
@@ -32,7 +34,7 @@ def main():
     K, c2w = synth.camera(H, W, 0)
     xs, ds = real_ldr.to_world(real_ldr.get_direction(K, (H, W)), c2w, False, device=dev)
     pos, nrm, uv, tri, valid = ray_intersect(scene, xs, ds)
-    mat = GpuStub()
+    mat = ngp_material(slf, dev) if args.material == "ngp" else GpuStub()
     bp = args.batch_pixels
 
     def f1(n_batches):
@@ -56,7 +58,7 @@ def main():
     em = sb.extract_emitters(scene, room["vertices"], room["faces"], views, threshold=5.0, device=dev)
     torch.cuda.synchronize(); t_em = time.perf_counter() - t0
     print(json.dumps({
-        "f1_refine_diffuse": {"pixels_per_batch": bp, "spp": args.spp, "indir_depth": args.depth, "ms_per_batch": round(t_f1 * 1e3, 2),
+        "f1_refine_diffuse": {"material": args.material, "pixels_per_batch": bp, "spp": args.spp, "indir_depth": args.depth, "ms_per_batch": round(t_f1 * 1e3, 2),
                               "Mpaths_per_s": round(bp * args.spp / t_f1 / 1e6, 1), "note": "first-bounce paths (each continues up to indir_depth bounces with NEE)"},
         "f2_bake_slf": {"views": args.views, "pixels": args.views * H * W, "seconds": round(t_slf, 3), "Mpixels_per_s": round(args.views * H * W / t_slf / 1e6, 1),
                         "occupied_voxels": int(sd["mask"].sum()), "note": "3 passes over the views (bounds, occupancy, pooling); every view is traced once and its hits are kept"},
