@@ -138,3 +138,58 @@ def test_refine_cli_writes_the_bake_file_set(tmp_path):
     import json as _json
     m = _json.load(open(os.path.join(out, "diffuse", "000.refined")))
     assert len(m["files"]) == 13 and m["run_key"]
+
+
+def test_refine_cli_runs_from_a_checkpoint(tmp_path):
+    """`python -m iris_amd.refine_shading --ckpt last.ckpt` WITHOUT --material: the material network is the reference's NGPBRDF, built from the SLF file's
+    (voxel_min, voxel_max) and the checkpoint's 'material.' weights exactly as refine_shading.py:82-92 does.  (Random parameters: no checkpoint of the reference
+    exists on this machine.)  The CLI's maps equal refine_view() called with the same network."""
+    from iris_amd import refine_shading as rs
+    from iris_amd import _lib as L
+    from iris_amd.model.brdf import load_ngpbrdf
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.model.slf import VoxelSLF
+    from iris_amd.utils import cameras, exr
+    from iris_amd.utils.path_tracing import load_scene
+    from iris_amd import bake_shading as bs
+    g = golden("bake_box.npz")
+    p = golden("pt_single.npz")
+    scene_dir = tmp_path / "scene"; scene_dir.mkdir()
+    with open(scene_dir / "scene.obj", "w") as fh:
+        for v in g["verts"]:
+            fh.write("v {} {} {}\n".format(*v))
+        for f in g["faces"]:
+            fh.write("f {} {} {}\n".format(*(f + 1)))
+    H, W = 8, 12
+    K = np.array([[0.8 * W, 0, W / 2.0], [0, 0.8 * W, H / 2.0], [0, 0, 1]], np.float32)
+    json.dump({"img_hw": [H, W], "views": [{"K": K.tolist(), "c2w": g["c2w"].tolist()}]}, open(tmp_path / "cams.json", "w"))
+    slf = VoxelSLF(torch.from_numpy(g["slf_mask"]), float(g["voxel_min"]), float(g["voxel_max"]))
+    slf.radiance[:] = torch.from_numpy(g["slf_radiance"])
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    torch.save({"is_emitter": torch.from_numpy(g["is_emitter"]), "emitter_vertices": torch.from_numpy(p["emitter_vertices"]), "emitter_area": torch.from_numpy(g["emitter_area"]),
+                "emitter_normal": torch.zeros(int(g["is_emitter"].sum()), 3), "emitter_radiance": torch.from_numpy(g["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(g["slf_mask"]), "voxel_min": float(g["voxel_min"]), "voxel_max": float(g["voxel_max"]), "weight": slf.state_dict()}, sp)
+    gen = torch.Generator().manual_seed(9)
+    params = (torch.rand(int(L.lib().iris_ngp_n_params()), generator=gen) * 2 - 1) * 0.3
+    ckpt = str(tmp_path / "last.ckpt")
+    torch.save({"state_dict": {"material.mlp.params": params, "emitter.radiance": torch.zeros(1, 3)}}, ckpt)       # the reference's checkpoint layout
+    out = str(tmp_path / "out")
+    argv = ["--scene", str(scene_dir), "--slf_path", sp, "--emitter_path", ep, "--output", out, "--dataset", "generic", "--cameras", str(tmp_path / "cams.json"),
+            "--ckpt", ckpt, "--spp_diffuse", "8", "--spp_specular", "4", "--indir_depth", "2", "--seed", "2", "--denoise", "none", "--compression", "none"]
+    rs.main(argv)
+    files = bs.output_files(out, 0)
+    assert len(files) == 13 and all(os.path.exists(f) for f in files)
+    # the same view through the library call with the same network and the CLI's per-view seed
+    dev = torch.device("cuda:0")
+    net = load_ngpbrdf(float(g["voxel_min"]), float(g["voxel_max"]), ckpt)
+    img_hw, views = cameras.load_generic(str(tmp_path / "cams.json"), 1.0)
+    sc = load_scene(str(scene_dir / "scene.obj"), device=dev)
+    em = SLFEmitter(ep, sp)
+    torch.manual_seed(2 * 1000003 + 0); torch.cuda.manual_seed(2 * 1000003 + 0)
+    xs, ds = cameras.view_rays(views[0], img_hw, dev)
+    ref = rs.refine_view(sc, em, net, xs, ds, 8, 4, 2)
+    got = exr.read_exr(files[0])
+    assert got.shape == (H, W, 3) and np.isfinite(got).all() and float(got.sum()) > 0
+    np.testing.assert_array_equal(got, ref["diffuse"].reshape(H, W, 3).cpu().numpy())
+    with pytest.raises(L.IrisError):
+        rs.main([a for a in argv if a not in ("--ckpt", ckpt)])          # neither --ckpt nor --material
