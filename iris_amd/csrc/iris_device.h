@@ -61,29 +61,12 @@ __device__ __forceinline__ f3 to_world(f3 l, f3 t, f3 b, f3 n) {
 // FIRST_QUADRANT: the caller guarantees x <= pi/2 + a few ulps (a polar angle): the same values from two selects instead of six.
 // (a double constant behind an optimisation barrier: it is materialised where it is used -- two scalar moves -- instead of being hoisted out of the
 //  sampling loop into a register pair that is then spilled to scratch and reloaded per sample)
-#ifndef IRIS_SINCOS_KD
-#define IRIS_SINCOS_KD 1
-#endif
 __device__ __forceinline__ double kd(double c) {
-#if IRIS_SINCOS_KD
     asm volatile("" : "+s"(c));
-#endif
     return c;
 }
 template <bool FIRST_QUADRANT = false>
 __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
-#ifdef IRIS_SINCOS_F32_EXPERIMENT    // (timing experiments only: the f32 sequence of rounds 1-3; different bits)
-    int j = (int)(x * 1.27323954473516f);
-    j = (j + 1) & ~1;
-    const float y = (float)j;
-    const float z = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    const float zz = z * z;
-    const float ps = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
-    const float pc = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
-    const int q = (j >> 1) & 3;
-    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
-    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
-#else
     const int j = (int)(x * 0.636619772367581343f + 0.5f);
     const double z = fma(-(double)j, kd(1.57079632679489661923), (double)x);     // |z| <= pi/4 (+ rounding of the quadrant choice)
     const double zz = z * z;
@@ -101,7 +84,6 @@ __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
     const int k = j & 3;
     s = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
     c = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
-#endif
 }
 // asin / acos on [0, 1] with a fully specified IEEE operation sequence (explicit fmaf, IEEE sqrtf, an integer-seeded Newton reciprocal):
 // the reference evaluates sin / cos of the ROUNDED polar angle theta = asin(sqrt(u0)) / acos(sqrt(c2)) (model/brdf.py:28, :50-51), and near grazing
