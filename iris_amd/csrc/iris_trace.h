@@ -287,15 +287,23 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
 // push logic).  Same arithmetic, same bits; the few lanes at other nodes sit the step out.  Measured +2.5 % at a threshold of 44 lanes (32: +0.7 %,
 // 38-47: +1.0 ... +1.2 % before the detection reused the loop head's ballot, 50: -0.4 %, 56: -2.2 %: below ~36 lanes the lanes sitting out cost more than
 // the shared visit saves, above ~48 the test itself -- two vector instructions in front of EVERY node step -- is paid too often for nothing).  0 = off.
+// The test costs two vector instructions and a scalar chain in front of a node step, and deep in the tree it never hits: after IRIS_SHARED_TRIES misses in a
+// row a wave skips it until its next refill (+1.3 ... +1.6 % on top: 1, 2, 3 misses equal, 4: +1.2 %, 8: +0.4 %; taking the reference lane from the rays of the
+// latest refill instead of the first lane at a node: no difference; a threshold of 36 / 40 with it: -0.4 / -0.6 %).
 #ifndef IRIS_SCALAR_TOP
 #define IRIS_SCALAR_TOP 44
 #endif
+#ifndef IRIS_SHARED_TRIES
+#define IRIS_SHARED_TRIES 2
+#endif
+constexpr int kSharedTries = IRIS_SHARED_TRIES;
 #if IRIS_SCALAR_TOP
 typedef __attribute__((address_space(4))) const uint32_t cst_u32;
 template <class STACK>
 __device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r, STACK& st, uint32_t off0) {
     // (inline asm: through a pointer hipcc proves the table global, falls back to four vector loads of the uniform address and turns the byte pairing
-    //  below back into v_perm_b32)
+    //  below back into v_perm_b32.  Issuing the load BEFORE the test, so that its latency runs under the compare / count / branch -- with a wait in the
+    //  path not taken, whose registers must not be reused while it is in flight --: no gain, -0.2 %.)
     typedef uint32_t iris_u16v __attribute__((ext_vector_type(16)));
     iris_u16v w;
     const uint64_t base = reinterpret_cast<uint64_t>(sc.nodes);
@@ -412,6 +420,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
     ray_begin(sc, r, r.o, r.d);
     r.cur = kEmptyRef;
     Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0; st.tid = tid;
+    int shared_tries = kSharedTries;   // wave-uniform: misses the shared-visit test may still have before it is skipped until the next refill
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
     int max_sp = 0;
@@ -427,6 +436,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 live = got = fetch(r.o, r.d);
             }
             if (__ballot(got) == 0) more = false;
+            shared_tries = kSharedTries;
             if (got) {
                 prepare(r.o, r.d);
                 ray_begin(sc, r, r.o, r.d);
@@ -447,13 +457,15 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
             if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
 #if IRIS_SCALAR_TOP
-            if (!COUNT && LAYOUT == kLayoutQ8) {
+            if (!COUNT && LAYOUT == kLayoutQ8 && shared_tries > 0) {
                 const uint32_t off = (r.cur << 6) + r.oct_base;                 // (meaningless in the lanes that are not at a node: masked out below)
                 const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __ffsll((long long)m_node) - 1);
                 if ((int)__popcll(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
                     if (at_node && off == off0) node_step_shared(sc, r, st, off0);
+                    shared_tries = kSharedTries;
                     continue;
                 }
+                --shared_tries;       // the wave has diverged: after kSharedTries misses in a row the test is skipped until the next refill brings rays that start together
             }
 #endif
             if (at_node) {
