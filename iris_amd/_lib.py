@@ -112,14 +112,16 @@ def lib():
 
 
 def source_hash():
-    """sha256 over the kernel sources, the ABI headers and the compiler flags embedded in the LOADED library (iris_debug_build_flags: -fno-slp-vectorize,
-    the scheduler strategy and the -D tuning overrides are worth several per cent): stamps profiles (tools/pmc_summary.py) so that bench.py can
-    refuse counters that were taken on other kernels or on another build of the same sources."""
+    """sha256 over the sources the BAKE kernels are compiled from (device / traversal / tile / bake headers, the host file that sizes and launches them, the BVH
+    builder, the ABI headers) and the compiler flags embedded in the LOADED library (iris_debug_build_flags: -fno-slp-vectorize, the scheduler strategy and the
+    -D tuning overrides are worth several per cent): stamps counter profiles (tools/pmc_summary.py) so that bench.py can refuse counters that were taken on other
+    kernels or on another build of the same sources.  (The headers of the other stages -- material network, shading cache, denoiser, path-tracing stages -- are
+    not part of the stamp: bake_view_kernel does not include them.)"""
     import hashlib
     h = hashlib.sha256()
     h.update(lib().iris_debug_build_flags())
     root = os.path.dirname(_HERE)
-    files = sorted(os.path.join("iris_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip", ".cpp")))
+    files = [os.path.join("iris_amd", "csrc", f) for f in ("bvh_build.cpp", "bvh_build.h", "iris_bake.h", "iris_device.h", "iris_hip.hip", "iris_tile.h", "iris_trace.h")]
     files += [os.path.join("include", "iris_hip.h"), os.path.join("include", "iris_hip_debug.h")]
     for f in files:
         h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())

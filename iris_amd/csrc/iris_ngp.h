@@ -72,28 +72,35 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(NgpArgs a) {
         if (dims < 3 && !hashed) hashed = true;       // (cannot happen: the loop only stops early once the stride exceeds the table)
     }
     _Float16 acc0 = (_Float16)0.f, acc1 = (_Float16)0.f;
+    // The 8 corners in the library's order (x fastest), two x-neighbours at a time.  What bounds this kernel is the number of 64-B requests its gathers send
+    // to the L2s (profiles/r4_ngp_pmc.json), and the two x-neighbours of a cell are adjacent table entries whenever the indexing lets them be -- always on a dense
+    // level, for even x on a hashed one (x ^ K and (x + 1) ^ K differ in bit 0 only) --: one 8-byte load then fetches both.
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float wgt = 1.0f;
-        uint32_t g[3];
+    for (int c = 0; c < 8; c += 2) {
+        uint32_t g1 = (c & 2) ? cell[1] + 1u : cell[1], g2 = (c & 4) ? cell[2] + 1u : cell[2];
+        uint32_t ia, ib;
+        if (hashed) { const uint32_t k = (g1 * 2654435761u) ^ (g2 * 805459861u); ia = (cell[0] * 1u) ^ k; ib = ((cell[0] + 1u) * 1u) ^ k; }
+        else { const uint32_t k = g1 * stride1 + g2 * stride2; ia = cell[0] + k; ib = cell[0] + 1u + k; }
+        ia %= size; ib %= size;
+        uint32_t ra, rb;
+        if (ib == ia + 1u) { const uint2 v = *reinterpret_cast<const uint2*>(table + ia); ra = v.x; rb = v.y; }
+        else if (ia == ib + 1u) { const uint2 v = *reinterpret_cast<const uint2*>(table + ib); ra = v.y; rb = v.x; }
+        else { ra = table[ia]; rb = table[ib]; }
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (c & (1 << d)) { wgt = wgt * w[d]; g[d] = cell[d] + 1u; }
-            else              { wgt = wgt * (1.0f - w[d]); g[d] = cell[d]; }
+        for (int xx = 0; xx < 2; ++xx) {
+            float wgt = 1.0f;
+            wgt = xx ? wgt * w[0] : wgt * (1.0f - w[0]);
+            wgt = (c & 2) ? wgt * w[1] : wgt * (1.0f - w[1]);
+            wgt = (c & 4) ? wgt * w[2] : wgt * (1.0f - w[2]);
+            const iris_h2v v = __builtin_bit_cast(iris_h2v, xx ? rb : ra);
+            // result += (half)(weight * value): every term rounded to half, the sum a half add.  The product is rounded to f32 FIRST and then to half, as a
+            // C compiler for any other target does it: behind the barrier hipcc cannot fold the multiplication into v_fma_mixlo_f16, which rounds the exact
+            // product to half once -- measured different from the two-step rounding in 1.4e-4 of the features (tests/test_ngp.py compares bit for bit).
+            float t0 = wgt * (float)v.x, t1 = wgt * (float)v.y;
+            asm volatile("" : "+v"(t0), "+v"(t1));
+            acc0 = (_Float16)((float)acc0 + (float)(_Float16)t0);
+            acc1 = (_Float16)((float)acc1 + (float)(_Float16)t1);
         }
-        uint32_t index;
-        if (hashed) index = (g[0] * 1u) ^ (g[1] * 2654435761u) ^ (g[2] * 805459861u);
-        else index = g[0] + g[1] * stride1 + g[2] * stride2;
-        index %= size;
-        const uint32_t raw = table[index];
-        const iris_h2v v = __builtin_bit_cast(iris_h2v, raw);
-        // result += (half)(weight * value): every term rounded to half, the sum a half add.  The product is rounded to f32 FIRST and then to half, as a
-        // C compiler for any other target does it: behind the barrier hipcc cannot fold the multiplication into v_fma_mixlo_f16, which rounds the exact
-        // product to half once -- measured different from the two-step rounding in 1.4e-4 of the features (tests/test_ngp.py compares bit for bit).
-        float t0 = wgt * (float)v.x, t1 = wgt * (float)v.y;
-        asm volatile("" : "+v"(t0), "+v"(t1));
-        acc0 = (_Float16)((float)acc0 + (float)(_Float16)t0);
-        acc1 = (_Float16)((float)acc1 + (float)(_Float16)t1);
     }
     iris_h2v o; o.x = acc0; o.y = acc1;
     a.feat[(size_t)level * a.n_chunk + i] = __builtin_bit_cast(uint32_t, o);
