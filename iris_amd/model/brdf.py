@@ -200,7 +200,10 @@ def load_ngpbrdf(voxel_min, voxel_max, ckpt):
     """The reference's loading sequence (refine_shading.py:83-92): NGPBRDF(voxel_min, voxel_max), the checkpoint's 'state_dict' entries under 'material.'
     with the prefix stripped, load_state_dict, frozen."""
     net = NGPBRDF(voxel_min, voxel_max)
-    state = torch.load(ckpt, map_location="cpu")["state_dict"]
+    try:
+        state = torch.load(ckpt, map_location="cpu")["state_dict"]
+    except Exception:     # noqa  (a Lightning checkpoint carries hyper-parameters and callback states that the tensors-only unpickler of recent torch refuses;
+        state = torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"]     #  the reference loads its own checkpoints with the full unpickler)
     weight = {k.replace("material.", ""): v for k, v in state.items() if "material." in k}
     net.load_state_dict(weight)
     for p in net.parameters():
