@@ -96,3 +96,39 @@ def test_block_order_equals_sorting_the_valid_rows():
             y, x = pix // W, pix % W
             key = ((y // block) * ((W + block - 1) // block) + x // block) * (block * block) + (y % block) * block + x % block
             assert torch.equal(sel, rows[torch.argsort(key)])
+
+
+def _worker_world1(port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from iris_amd import sharding as sh
+        H, W = 21, 9                                             # (rows not a multiple of the stripe height)
+        g = torch.Generator().manual_seed(1)
+        local = torch.rand(5, H * W, 3, generator=g)
+        for mode in ("gather", "all_gather"):
+            ga = sh.MapGatherer(H, W, 1, 0, 5, "cpu", mode=mode, force_collective=True)
+            assert ga.collective and ga.receives
+            for k in range(2):
+                full = ga(local * (k + 1))
+                assert full is ga.full and torch.equal(full, local * (k + 1))
+        assert sh.MapGatherer(H, W, 1, 0, 5, "cpu").collective is False
+        assert sh.gather_maps(local, H, W, 1, 0) is local
+        assert torch.equal(sh.gather_maps(local, H, W, 1, 0, force_collective=True), local)
+        q.put(True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_forced_collective_at_world_one():
+    """force_collective (bench.py IRIS_BENCH_FORCE_PG=1): a world of one still goes through the send buffer, the collective and the permutation -- here over gloo on
+    the CPU; the same branch over RCCL on the GPU is tests/test_rccl_world1.py"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_world1, args=(free_port(), q))
+    p.start()
+    assert q.get(timeout=100) is True
+    p.join(timeout=30)
+    assert p.exitcode == 0
