@@ -107,9 +107,13 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--graph", action="store_true", help="capture the training step in a HIP graph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--material", choices=["ngp", "stub"], default="ngp")
+    ap.add_argument("--pt-tile-min", type=int, default=-1, help="iris_debug_set pt_tile_min: calls of at least this many rays go through the tiled tracing stages (default: the library's)")
     args = ap.parse_args()
     import bench
     dev = torch.device("cuda:0")
+    if args.pt_tile_min >= 0:
+        from iris_amd import _lib as L
+        L.debug_set("pt_tile_min", args.pt_tile_min)
     ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
     room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
     print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph, material=args.material)))
