@@ -33,14 +33,15 @@ static __device__ __forceinline__ unsigned long long stamp_real() {
 
 // ------------------------------------------------------------------------------------------------ VALU issue
 // 32 independent instructions per loop trip on 16 destination registers (two passes), sources that never change.
-enum { OP_FMA = 0, OP_FMA_MIX, OP_PERM, OP_CNDMASK, OP_MAX, OP_MIN3, OP_CMP, OP_MUL, OP_ADD_U32, OP_LSHL_ADD, OP_RCP, OP_MED3, OP_PK_FMA, OP_CND_SGPR, OP_CND_DST, OP_CMP_CND, OP_CMP_E64, OP_BFI, OP_MINMAX, OP_AND_OR, OP_MOV, OP_CVT_UB0, OP_CVT_UB2, OP_CVT_U32, OP_BFE, OP_AND, OP_OR, OP_LSHL, OP_LSHR, OP_SUB_F32, OP_ADD_F32, OP_MIN_U32, OP_MAX3, OP_LDEXP, OP_MAD_U24, OP_MUL_U24, OP_CVT_F16, OP_CND_E64_VCC, OP_CMP_NOP_CND, OP_MAD_MIX_LO, OP_MUL_LO_U32, OP_MUL_HI_U32, OP_MAD_U64, OP_N };
+enum { OP_FMA = 0, OP_FMA_MIX, OP_PERM, OP_CNDMASK, OP_MAX, OP_MIN3, OP_CMP, OP_MUL, OP_ADD_U32, OP_LSHL_ADD, OP_RCP, OP_MED3, OP_PK_FMA, OP_CND_SGPR, OP_CND_DST, OP_CMP_CND, OP_CMP_E64, OP_BFI, OP_MINMAX, OP_AND_OR, OP_MOV, OP_CVT_UB0, OP_CVT_UB2, OP_CVT_U32, OP_BFE, OP_AND, OP_OR, OP_LSHL, OP_LSHR, OP_SUB_F32, OP_ADD_F32, OP_MIN_U32, OP_MAX3, OP_LDEXP, OP_MAD_U24, OP_MUL_U24, OP_CVT_F16, OP_CND_E64_VCC, OP_CMP_NOP_CND, OP_MAD_MIX_LO, OP_MUL_LO_U32, OP_MUL_HI_U32, OP_MAD_U64, OP_PK_FMA_F16, OP_PK_MAX_F16, OP_PK_ADD_F16, OP_CVT_PKRTZ, OP_PK_MIN_F16_PK_FMA, OP_N };
 static const char* kOpName[OP_N] = {"v_fma_f32", "v_fma_mix_f32", "v_perm_b32", "v_cndmask_b32", "v_max_f32", "v_min3_f32", "v_cmp_lt_f32",
                                     "v_mul_f32", "v_add_u32", "v_lshl_add_u32", "v_rcp_f32", "v_med3_f32", "v_pk_fma_f32",
                                     "v_cndmask_b32_e64(sgpr mask)", "v_cndmask_b32(dst!=src)", "v_cmp+3xv_cndmask", "v_cmp_lt_f32_e64(sgpr dst)", "v_bfi_b32",
                                     "v_min_f32+v_max_f32", "v_and_or_b32", "v_mov_b32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte2", "v_cvt_f32_u32", "v_bfe_u32", "v_and_b32", "v_or_b32",
                                     "v_lshlrev_b32", "v_lshrrev_b32", "v_sub_f32", "v_add_f32", "v_min_u32", "v_max3_f32", "v_ldexp_f32", "v_mad_u32_u24", "v_mul_u32_u24",
                                     "v_cvt_f32_f16", "v_cndmask_b32_e64(vcc operand)", "v_cmp_e32+4 fma+v_cndmask_e32", "v_fma_mix_f32(f32 srcs)",
-                                    "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32"};
+                                    "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32",
+                                    "v_pk_fma_f16", "v_pk_max_f16", "v_pk_add_f16", "v_cvt_pkrtz_f16_f32", "v_pk_min_f16+v_pk_fma_f16"};
 
 #define R16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
@@ -105,7 +106,13 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, unsign
     else if (OP == OP_MAD_MIX_LO) asm volatile("v_fma_mix_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));                       \
     else if (OP == OP_MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));                                    \
     else if (OP == OP_MUL_HI_U32) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));                                    \
-    else if (OP == OP_MAD_U64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p[k]) : "v"(b), "v"(c) : "vcc");
+    else if (OP == OP_MAD_U64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p[k]) : "v"(b), "v"(c) : "vcc");               \
+    else if (OP == OP_PK_FMA_F16) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));                          \
+    else if (OP == OP_PK_MAX_F16) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[k]) : "v"(b));                                      \
+    else if (OP == OP_PK_ADD_F16) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(a[k]) : "v"(b));                                      \
+    else if (OP == OP_CVT_PKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(a[k]) : "v"(b), "v"(c));                        \
+    else if (OP == OP_PK_MIN_F16_PK_FMA) { if (k & 1) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a[k]) : "v"(b));                  \
+                                           else asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c)); }
         R16(ONE) R16(ONE)
 #undef ONE
     }
@@ -403,6 +410,16 @@ int main(int argc, char** argv) {
             run_valu<OP_MUL_LO_U32>(cus, w, d_out, d_cyc, d_real);
             run_valu<OP_MUL_HI_U32>(cus, w, d_out, d_cyc, d_real);
             run_valu<OP_MAD_U64>(cus, w, d_out, d_cyc, d_real);
+        }
+    }
+    if (!strcmp(what, "pk16")) {          // packed half arithmetic (round 4: would slab tests in packed f16 issue faster than v_fma_mix_f32?)
+        for (int w : {2, 7}) {
+            run_valu<OP_FMA_MIX>(cus, w, d_out, d_cyc, d_real);
+            run_valu<OP_PK_FMA_F16>(cus, w, d_out, d_cyc, d_real);
+            run_valu<OP_PK_MAX_F16>(cus, w, d_out, d_cyc, d_real);
+            run_valu<OP_PK_ADD_F16>(cus, w, d_out, d_cyc, d_real);
+            run_valu<OP_CVT_PKRTZ>(cus, w, d_out, d_cyc, d_real);
+            run_valu<OP_PK_MIN_F16_PK_FMA>(cus, w, d_out, d_cyc, d_real);
         }
     }
     if (all || !strcmp(what, "gather")) {
