@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
     const char* cm = getenv("BVH_EVAL_CULL");   // unset: as the kernels (no distances on the stack); "exact": skip popped entries whose entry distance exceeds the best hit; "<m>": the same through a code of exponent + m mantissa bits
     const int cull_bits = !cm ? -2 : (!strcmp(cm, "exact") ? -1 : atoi(cm));
     long long skipped_nodes = 0, skipped_leaves = 0;
+    const bool seed_pass = getenv("BVH_EVAL_SEED") != nullptr;
     auto code = [&](float t) -> uint32_t { uint32_t b; memcpy(&b, &t, 4); return b >> (23 - cull_bits); };
     auto pop = [&](int& sp, float best) -> uint32_t {
         while (sp) {
@@ -107,6 +108,10 @@ int main(int argc, char** argv) {
         o = {o.x + 8.94e-5f * d.x, o.y + 8.94e-5f * d.y, o.z + 8.94e-5f * d.z};
         const float id[3] = {1.f / d.x, 1.f / d.y, 1.f / d.z}, oo[3] = {o.x, o.y, o.z};
         float best = INFINITY;
+        // BVH_EVAL_SEED=1: upper bound for any hit predictor -- trace once uncounted, then count the traversal that STARTS with the true hit distance as its bound
+        for (int pass = seed_pass ? 0 : 1; pass < 2; ++pass) {
+        const long long n0 = tot_nodes, t0c = tot_tris;
+        if (pass == 1 && seed_pass) best = best < INFINITY ? best * 1.0001f : best; else best = INFINITY;
         int sp = 0;
         uint32_t cur = 0;   // node index, or 0x80000000 | start << 3 | count
         for (;;) {
@@ -141,6 +146,8 @@ int main(int argc, char** argv) {
             for (int i = m - 1; i >= 1; --i) { dstack[sp] = key[i]; stack[sp++] = ref[i]; }
             max_sp = std::max<long long>(max_sp, sp);
             cur = ref[0];
+        }
+        if (pass == 0) { tot_nodes = n0; tot_tris = t0c; }
         }
         hits += best < INFINITY;
     }
