@@ -67,6 +67,39 @@ def main():
         pos = gb["position"]
         pos = pos.repeat((N + pos.shape[0] - 1) // pos.shape[0], 1)[:N].contiguous()
         run(pos, "primary_hits_of_a_1080p_view")
+        # the same surface points in RANDOM order (what a later bounce of the refine integrators feeds), and what sorting them along a Morton curve first would buy
+        # (prototype in torch: 10 bits per axis; sort + gather + scatter-back timed separately)
+        perm0 = torch.randperm(N, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        pos_r = pos[perm0].contiguous()
+        run(pos_r, "surface_points_random_order")
+
+        def morton_perm(p):
+            q = ((p + 3.0) * (1024.0 / 6.0)).to(torch.int64).clamp_(0, 1023)
+            def spread(v):
+                v = (v | (v << 16)) & 0x030000FF
+                v = (v | (v << 8)) & 0x0300F00F
+                v = (v | (v << 4)) & 0x030C30C3
+                v = (v | (v << 2)) & 0x09249249
+                return v
+            code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+            return torch.sort(code.to(torch.int32)).indices
+        pm = morton_perm(pos_r)
+        run(pos_r[pm].contiguous(), "surface_points_morton_sorted")
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ref = net(pos_r)
+        e0.record()
+        for _ in range(args.steps):
+            pm = morton_perm(pos_r)
+        e1.record()
+        for _ in range(args.steps):
+            o = net(pos_r[pm])
+            back = {k: torch.empty_like(v).index_copy_(0, pm, v) for k, v in o.items()}
+        e2.record()
+        torch.cuda.synchronize()
+        out["surface_points_morton_sorted"]["sort_ms_torch_prototype"] = round(e0.elapsed_time(e1) / args.steps, 3)
+        out["surface_points_morton_sorted"]["gather_forward_scatter_ms"] = round(e1.elapsed_time(e2) / args.steps, 3)
+        out["surface_points_morton_sorted"]["same_bits_as_unsorted"] = bool(all(torch.equal(back[k], ref[k]) for k in ref))
     except Exception as e:     # noqa
         out["primary_hits_of_a_1080p_view"] = {"skipped": repr(e)}
     print(json.dumps(out))
