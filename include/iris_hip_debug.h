@@ -27,7 +27,8 @@ enum { IRIS_BAKE_AUTO = 0, IRIS_BAKE_PIXEL_PER_WAVE = 1, IRIS_BAKE_TILE_SORTED =
  *            {rays, node visits, triangle tests, wave-level node steps, wave-level triangle steps, rays whose stack exceeded
  *            8 / 12 / 16 entries, tail sum (pixel-per-wave), node visits / wave-level node steps while a tile drains,
  *            node visits with node index < 21 / 85 / 341 / 1365, wave-level node steps in which >= 32 of the lanes at a node sit at
- *            the SAME node of the same octant table / the lanes that share it / the steps in which all of them do, 0, 0};
+ *            the SAME node of the same octant table / the lanes that share it / the steps in which all of them do, wave-level node steps
+ *            that could not take the branch-free pushes (a lane's stack within three entries of the LDS part's end), 0};
  *   variant  IRIS_BAKE_*.  All variants and the instrumented builds return identical bits. */
 IRIS_API int iris_debug_bake_diffuse(const iris_scene *, const iris_emitter *, const iris_slf *, const float *pos, const float *nrm,
                             int64_t P, int spp, const float *u2, uint64_t seed, uint32_t stream_id, const int32_t *pix_id,

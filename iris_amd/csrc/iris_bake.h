@@ -133,8 +133,8 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 11 + k, (unsigned long long)x);
         }
-        uint32_t sh[3] = {ts.shared_iters, ts.shared_lanes, ts.shared_all_iters};
-        for (int k = 0; k < 3; ++k) {
+        uint32_t sh[4] = {ts.shared_iters, ts.shared_lanes, ts.shared_all_iters, ts.slow_push_iters};
+        for (int k = 0; k < 4; ++k) {
             uint32_t x = sh[k];
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 15 + k, (unsigned long long)x);
@@ -196,10 +196,10 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 
 // ------------------------------------------------------------------------------------------------------- tile kernels
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU): 7 x 20 488 B of LDS, 72 VGPRs.
-#define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s
+#define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s  (LDS now 7 x 22 536 B: 12-entry stacks)
 #endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
-#define IRIS_TILE_STACK 10       // (a.stack_ovf), NOT to private scratch: without a scratch-resident stack array the kernel fits 6 (7) waves/SIMD (measured +6.5 %)
+#define IRIS_TILE_STACK 12       // (a.stack_ovf), NOT to private scratch: without a scratch-resident stack array the kernel fits 6 (7) waves/SIMD (measured +6.5 %)
 #endif
 
 // One tile (<= kTileRays rays = the np <= tile_px consecutive valid pixels from p0 on, x spp) of one lobe, by one 256-thread workgroup.

@@ -63,6 +63,16 @@ struct Stack {
         else spill[min(sp - LDS_DEPTH, kStackCapacity - LDS_DEPTH - 1)] = v;
         ++sp;
     }
+    // Three pushes without a branch (the caller has checked, for the whole wave, that sp <= LDS_DEPTH - 3): every reference is WRITTEN at the current top and the
+    // top moves only if its condition holds (t >= 0) -- a reference that is not pushed leaves garbage in a free slot.  No execution masks, no overflow tests.
+    __device__ __forceinline__ void push3_fast(uint32_t v3, int32_t t3, uint32_t v2, int32_t t2, uint32_t v1, int32_t t1) {
+        int u = sp;
+        lds[u * kBlock] = v3; u += 1 + (t3 >> 31);
+        lds[u * kBlock] = v2; u += 1 + (t2 >> 31);
+        lds[u * kBlock] = v1; u += 1 + (t1 >> 31);
+        sp = u;
+    }
+    __device__ __forceinline__ uint32_t pop_lds() { --sp; return lds[sp * kBlock]; }   // (the caller knows that the top is in LDS)
     __device__ __forceinline__ uint32_t pop() {
         --sp;
         if (sp < LDS_DEPTH) return lds[sp * kBlock];
@@ -71,6 +81,9 @@ struct Stack {
     }
 };
 
+#ifndef IRIS_TRI_FLAT
+#define IRIS_TRI_FLAT 1
+#endif
 // Watertight ray / triangle test (Woop, Benthin, Wald 2013, "Watertight Ray/Triangle Intersection", JCGT 2(1), section 3): the ray is
 // made the z axis of a sheared, axis-permuted space -- kz = the axis of d's largest magnitude, (kx, ky) the two after it, S = (d[kx], d[ky], 1) / d[kz]
 // --, every vertex is translated by the origin and sheared by the same function of (vertex, ray) in whichever triangle it appears, and the
@@ -122,9 +135,18 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const Ray
     const float u = V * inv_det, v = W * inv_det;
     // no two edge functions of strictly opposite sign; det == 0 gives t = NaN or +-inf: a NaN fails every comparison, and +inf can only tie with the
     // initial h.t, whose h.id = INT_MIN no index is smaller than
+#if IRIS_TRI_FLAT
+    // (bitwise, not short-circuit: as `&&` / `||` hipcc turns the acceptance test into four divergent branches with their execution-mask bookkeeping -- ~25 scalar
+    //  instructions per triangle test; the same comparisons combined as masks are five compares and four scalar mask operations)
+    const bool mixed = (int)(fminf(fminf(U, V), W) < 0.f) & (int)(fmaxf(fmaxf(U, V), W) > 0.f);
+    const bool ok = (int)!mixed & (int)(t >= 0.f);
+    const bool closer = (int)(t < h.t) | ((int)(t == h.t) & (int)(id < h.id));       // closest hit = lexicographic min of (t, original index)
+    if ((int)ok & (int)closer) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
+#else
     const bool ok = !(fminf(fminf(U, V), W) < 0.f && fmaxf(fmaxf(U, V), W) > 0.f) && t >= 0.f;
     // closest hit = lexicographic min of (t, original index)
     if (ok && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -138,6 +160,30 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const Ray
 // (Loop control: `__popcll(m) >= k` stays a 64-bit comparison, which the scalar ALU cannot do, so hipcc runs it on the vector ALU -- v_cmp_lt_u64 on scalar
 //  operands, in front of every node and leaf step.  Counting the two mask halves with 32-bit scalar instructions instead was measured SLOWER, -0.8 %: the longer
 //  scalar dependency chain in front of the step costs more than the vector issue slot, EXPERIMENTS.md round 4.)
+#ifndef IRIS_POPC_ASM
+#define IRIS_POPC_ASM 1
+#endif
+#ifndef IRIS_IDLE_GATE
+#define IRIS_IDLE_GATE 1
+#endif
+#ifndef IRIS_LOOP_NEST
+#define IRIS_LOOP_NEST 1
+#endif
+#ifndef IRIS_FAST_PUSH
+#define IRIS_FAST_PUSH 1
+#endif
+#ifndef IRIS_FAST_POP
+#define IRIS_FAST_POP 1
+#endif
+__device__ __forceinline__ int popc_mask(unsigned long long m) {
+#if IRIS_POPC_ASM
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");     // ONE scalar instruction and a 32-bit result: the comparison that follows stays on the scalar ALU
+    return n;
+#else
+    return (int)__popcll(m);
+#endif
+}
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
     return (int)(threadIdx.x & 63) == (__ffsll((long long)m) - 1);
@@ -153,6 +199,7 @@ struct TraceStats {
     uint32_t drain_nodes = 0, drain_node_iters = 0; // trace_stream: the same two node counters while the ray list is exhausted (no refill)
     uint32_t top21 = 0, top85 = 0, top341 = 0, top1365 = 0;   // node visits with node index < 21 / 85 / 341 / 1365 (nodes are in breadth-first order:
                                                               // the first 1 + 4 + 16 (+ 64 (+ 256 (+ 1024))) nodes are the top 3 (4, 5, 6) levels of a full tree)
+    uint32_t slow_push_iters = 0;     // wave node iterations that could not take the branch-free pushes (some lane's stack within three entries of the LDS part's end)
     uint32_t shared_iters = 0, shared_lanes = 0, shared_all_iters = 0;   // wave node iterations in which >= 32 of the lanes at a node sit at the SAME node of the same
                                                                           // octant table (counted by the first active lane), the lanes that share it, and the
                                                                           // iterations in which every lane at a node does
@@ -201,7 +248,7 @@ __device__ __forceinline__ void ray_begin(const SceneDev& sc, RayState& r, f3 o,
 
 // One internal-node visit of the lanes that are at a node: 4 slab tests, 5-comparator sorting network, near child first.
 template <int LAYOUT, class STACK>
-__device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK& st) {
+__device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK& st, bool fast_push = false) {
     float k0, k1, k2, k3;
     uint32_t r0, r1, r2, r3;
     const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
@@ -242,6 +289,15 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // (the references are needed whichever child is hit: this keeps their load with the plane loads instead of behind the hit test, where hipcc
         //  sinks it otherwise -- a second dependent round trip per visit, measured -8 %)
         asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        if (fast_push) {                                        // (wave-uniform)
+            uint32_t c = b2 >= 0 ? r2 : r3;
+            c = b1 >= 0 ? r1 : c;
+            c = b0 >= 0 ? r0 : c;
+            st.push3_fast(r3, b3 | n012, r2, b2 | n01, r1, b1 | b0);      // (no child hit: every condition's sign is set, nothing moves)
+            if ((n012 & b3) >= 0) r.cur = c;
+            else r.cur = st.sp > 0 ? st.pop_lds() : kEmptyRef;       // (a branch-free pop -- every lane reads the entry below its top, selects afterwards -- was measured -2 %:
+            return;                                                  //  it puts an LDS round trip behind EVERY node step)
+        }
         if ((n012 & b3) >= 0) {
             uint32_t c = b2 >= 0 ? r2 : r3;                     // (selects, written innermost first: as a nested ?: hipcc makes this three branches)
             c = b1 >= 0 ? r1 : c;
@@ -297,10 +353,13 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
 #define IRIS_SHARED_TRIES 2
 #endif
 constexpr int kSharedTries = IRIS_SHARED_TRIES;
+#ifndef IRIS_SHARED_PAIRS
+#define IRIS_SHARED_PAIRS 1
+#endif
 #if IRIS_SCALAR_TOP
 typedef __attribute__((address_space(4))) const uint32_t cst_u32;
 template <class STACK>
-__device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r, STACK& st, uint32_t off0) {
+__device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r, STACK& st, uint32_t off0, bool fast_push = false) {
     // (inline asm: through a pointer hipcc proves the table global, falls back to four vector loads of the uniform address and turns the byte pairing
     //  below back into v_perm_b32.  Issuing the load BEFORE the test, so that its latency runs under the compare / count / branch -- with a wait in the
     //  path not taken, whose registers must not be reused while it is in flight --: no gain, -0.2 %.)
@@ -313,8 +372,33 @@ __device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r
     uint32_t r0 = w[12], r1 = w[13], r2 = w[14], r3 = w[15];
     const float ax = __uint_as_float(w[3]) * ix, ay = __uint_as_float(w[4]) * iy, az = __uint_as_float(w[5]) * iz;
     const float bx = fmaf(__uint_as_float(w[0]), ix, nx), by = fmaf(__uint_as_float(w[1]), iy, ny), bz = fmaf(__uint_as_float(w[2]), iz, nz);
-    const uint32_t nxq = w[6], nyq = w[7], nzq = w[8], fxq = w[9], fyq = w[10], fzq = w[11];
     typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
+#if IRIS_SHARED_PAIRS
+    // Bytes 0 / 2 and 1 / 3 of a plane word are isolated TOGETHER: w & 0x00ff00ff holds the planes of children 0 and 2 as the two f16 halves of one
+    // scalar register, (w >> 8) & 0x00ff00ff those of children 1 and 3 -- on register PAIRS (the six plane words are adjacent), 9 scalar instructions
+    // instead of the 24 single-byte extractions hipcc writes (asm: the compiler sees through the masks and goes back to single bytes).
+    uint64_t m02[3], m13[3];
+    const uint64_t kMask = 0x00ff00ff00ff00ffull;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m13[k] = (uint64_t)w[6 + 2 * k] | ((uint64_t)w[7 + 2 * k] << 32);           // (in place: the word pair is dead afterwards)
+        asm("s_and_b64 %0, %1, %2\n\ts_lshr_b64 %1, %1, 8\n\ts_and_b64 %1, %1, %2" : "=&s"(m02[k]), "+s"(m13[k]) : "s"(kMask) : "scc");
+    }
+    // words in table order: near x, near y | near z, far x | far y, far z
+#define IRIS_H2(M, K, HI) __builtin_bit_cast(iris_h2, (uint32_t)((M)[K] >> ((HI) ? 32 : 0)))
+#define IRIS_SLABS2(D, M, SEL)                                                                                                   \
+    {                                                                                                                             \
+        const iris_h2 qnx = IRIS_H2(M, 0, 0), qny = IRIS_H2(M, 0, 1), qnz = IRIS_H2(M, 1, 0), qfx = IRIS_H2(M, 1, 1), qfy = IRIS_H2(M, 2, 0), qfz = IRIS_H2(M, 2, 1); \
+        float tn = fmaxf(fmaxf(fmaf((float)qnx.SEL, ax, bx), fmaf((float)qny.SEL, ay, by)), fmaxf(fmaf((float)qnz.SEL, az, bz), 0.f));   \
+        float tf = fminf(fminf(fmaf((float)qfx.SEL, ax, bx), fmaf((float)qfy.SEL, ay, by)), fminf(fmaf((float)qfz.SEL, az, bz), r.h.t)); \
+        D = tf - tn;                                                                                                              \
+    }
+    float d0, d1, d2, d3;
+    IRIS_SLABS2(d0, m02, x) IRIS_SLABS2(d1, m13, x) IRIS_SLABS2(d2, m02, y) IRIS_SLABS2(d3, m13, y)
+#undef IRIS_SLABS2
+#undef IRIS_H2
+#else
+    const uint32_t nxq = w[6], nyq = w[7], nzq = w[8], fxq = w[9], fyq = w[10], fzq = w[11];
 #define IRIS_PAIR(NQ, FQ, C) __builtin_bit_cast(iris_h2, (uint32_t)((((NQ) >> (8 * (C))) & 0xffu) | ((((FQ) >> (8 * (C))) & 0xffu) << 16)))
 #define IRIS_SLABS(D, C)                                                                                                          \
     {                                                                                                                             \
@@ -327,8 +411,18 @@ __device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r
     IRIS_SLABS(d0, 0) IRIS_SLABS(d1, 1) IRIS_SLABS(d2, 2) IRIS_SLABS(d3, 3)
 #undef IRIS_SLABS
 #undef IRIS_PAIR
+#endif
     const int32_t b0 = __float_as_int(d0), b1 = __float_as_int(d1), b2 = __float_as_int(d2), b3 = __float_as_int(d3);
     const int32_t n01 = b0 & b1, n012 = n01 & b2;
+    if (fast_push) {
+        uint32_t c = b2 >= 0 ? r2 : r3;
+        c = b1 >= 0 ? r1 : c;
+        c = b0 >= 0 ? r0 : c;
+        st.push3_fast(r3, b3 | n012, r2, b2 | n01, r1, b1 | b0);
+        if ((n012 & b3) >= 0) r.cur = c;
+        else r.cur = st.sp > 0 ? st.pop_lds() : kEmptyRef;
+        return;
+    }
     if ((n012 & b3) >= 0) {
         uint32_t c = b2 >= 0 ? r2 : r3;
         c = b1 >= 0 ? r1 : c;
@@ -352,10 +446,13 @@ __device__ __forceinline__ RayXf leaf_phase_xform(const RayState& r) {
     return x;
 }
 template <class STACK>
-__device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, const RayXf& xf, STACK& st) {
+__device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, const RayXf& xf, STACK& st, bool lds_only = false) {
     tri_test(sc, (int)((r.cur & 0x7fffffffu) >> 3), xf, r.h);
     r.cur += 7u;                                                  // leaf ref = leafbit | start << 3 | count: start + 1, count - 1
-    if ((r.cur & 7u) == 0u) r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+    if ((r.cur & 7u) == 0u) {
+        if (lds_only) r.cur = st.sp > 0 ? st.pop_lds() : kEmptyRef;      // (wave-uniform: no lane of the step has entries beyond the LDS part)
+        else r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+    }
 }
 
 // One ray per lane, run to completion (primary rays, the path-tracing stages, the pixel-per-wave bake kernel).
@@ -452,16 +549,34 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
         for (;;) {
             const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
             const unsigned long long m_node = __ballot(at_node);
+#if IRIS_LOOP_NEST
+            // (nested tests with an empty asm in front of each inner one: hipcc otherwise folds them into ONE boolean -- s_cselect / s_and / s_or on mask pairs and a
+            //  v_cmp on a 64-bit count -- where each test is a scalar compare and a branch)
+            const int n_node = popc_mask(m_node);
+            if (n_node == 0) break;
+            if (n_node < kPhaseMinRt) {
+                asm volatile("");
+                if (popc_mask(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
+            }
+            if (n_node <= 64 - kRefillMin) {
+                asm volatile("");
+                if (more) {
+                    asm volatile("");
+                    if (popc_mask(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
+                }
+            }
+#else
             const int n_node = __popcll(m_node);
             if (n_node == 0) break;
             if (n_node < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && (r.cur & kLeafBit))) >= kPhaseMinRt) break;
-            if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
+            if ((!IRIS_IDLE_GATE || n_node <= 64 - kRefillMin) && more && popc_mask(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
+#endif
 #if IRIS_SCALAR_TOP
             if (!COUNT && LAYOUT == kLayoutQ8 && shared_tries > 0) {
                 const uint32_t off = (r.cur << 6) + r.oct_base;                 // (meaningless in the lanes that are not at a node: masked out below)
                 const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __ffsll((long long)m_node) - 1);
-                if ((int)__popcll(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
-                    if (at_node && off == off0) node_step_shared(sc, r, st, off0);
+                if (popc_mask(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
+                    if (at_node && off == off0) node_step_shared(sc, r, st, off0, IRIS_FAST_PUSH && LDS_DEPTH >= 3 && __ballot(st.sp > LDS_DEPTH - 3) == 0);
                     shared_tries = kSharedTries;
                     continue;
                 }
@@ -470,7 +585,9 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
 #endif
             if (at_node) {
                 if (COUNT) { ts->nodes++; ts->count_top(r.cur); ts->count_shared(r.cur, r.oct_base); if (first_active_lane()) ts->node_iters++; if (!more) { ts->drain_nodes++; if (first_active_lane()) ts->drain_node_iters++; } }
-                node_step<LAYOUT>(sc, r, st);
+                const bool fast_push = IRIS_FAST_PUSH && LDS_DEPTH >= 3 && __ballot(st.sp > LDS_DEPTH - 3) == 0;
+                if (COUNT && !fast_push && first_active_lane()) ts->slow_push_iters++;
+                node_step<LAYOUT>(sc, r, st, fast_push);
                 if (COUNT) max_sp = max(max_sp, st.sp);
             }
         }
@@ -478,13 +595,29 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
         const RayXf xf = leaf_phase_xform(r);
         for (;;) {
             const bool at_leaf = r.cur != kEmptyRef && (r.cur & kLeafBit);
+#if IRIS_LOOP_NEST
+            const int n_leaf = popc_mask(__ballot(at_leaf));
+            if (n_leaf == 0) break;
+            if (n_leaf < kPhaseMinRt) {
+                asm volatile("");
+                if (popc_mask(__ballot(r.cur != kEmptyRef && !(r.cur & kLeafBit))) >= kPhaseMinRt) break;
+            }
+            if (n_leaf <= 64 - kRefillMin) {
+                asm volatile("");
+                if (more) {
+                    asm volatile("");
+                    if (popc_mask(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;
+                }
+            }
+#else
             const int n_leaf = __popcll(__ballot(at_leaf));
             if (n_leaf == 0) break;
             if (n_leaf < kPhaseMinRt && __popcll(__ballot(r.cur != kEmptyRef && !(r.cur & kLeafBit))) >= kPhaseMinRt) break;
-            if (more && __popcll(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;
+            if ((!IRIS_IDLE_GATE || n_leaf <= 64 - kRefillMin) && more && popc_mask(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;
+#endif
             if (at_leaf) {
                 if (COUNT) { ts->tris++; if (first_active_lane()) ts->leaf_iters++; }
-                leaf_step(sc, r, xf, st);
+                leaf_step(sc, r, xf, st, IRIS_FAST_POP && __ballot(st.sp > LDS_DEPTH) == 0);
             }
         }
     }

@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 STAT_NAMES = ["rays", "node_visits", "tri_tests", "wave_node_iters", "wave_leaf_iters", "sp_gt8", "sp_gt12", "sp_gt16", "tail_sum",
-              "drain_node_visits", "drain_wave_node_iters", "top21", "top85", "top341", "top1365", "unused"]
+              "drain_node_visits", "drain_wave_node_iters", "top21", "top85", "top341", "top1365", "shared_iters", "shared_lanes", "shared_all_iters", "slow_push_iters"]
 
 
 def check_invariants(st, expected_rays):
