@@ -574,7 +574,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
 #if IRIS_SCALAR_TOP
             if (!COUNT && LAYOUT == kLayoutQ8 && shared_tries > 0) {
                 const uint32_t off = (r.cur << 6) + r.oct_base;                 // (meaningless in the lanes that are not at a node: masked out below)
-                const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __ffsll((long long)m_node) - 1);
+                const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __builtin_ctzll(m_node));   // (m_node != 0 here: ctz, not ffs - 1 with its zero case)
                 if (popc_mask(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
                     if (at_node && off == off0) node_step_shared(sc, r, st, off0, IRIS_FAST_PUSH && LDS_DEPTH >= 3 && __ballot(st.sp > LDS_DEPTH - 3) == 0);
                     shared_tries = kSharedTries;
