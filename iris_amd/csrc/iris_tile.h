@@ -103,7 +103,8 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
             int base = 0;
             if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_chunk, __popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+            // (v_mbcnt: the claiming lanes below this one, without the 64-bit lane mask -- a tile-long value hipcc kept in scratch and reloaded in every refill round)
+            const int i = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (i >= nr) return false;
             my_r = s_sorted[i];
             fetch_ray(my_r, o, d);
