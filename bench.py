@@ -423,8 +423,11 @@ def main():
             roofs = {
                 "valu": {"achieved": round(valu_prof, 1), "peak": round(valu_peak, 1), "unit": "G VALU issue quad-cycles/s", "frac": round(valu_prof / valu_peak, 4),
                          "frac_with_this_runs_ray_rate": round(valu_ach / valu_peak, 4),
+                         "frac_at_2400_MHz": round(valu_prof / (N_SIMD * 2.4e9 / 4 / 1e9), 4),
+                         "this_runs_rate_at_2400_MHz": round(valu_ach / (N_SIMD * 2.4e9 / 4 / 1e9), 4),
                          "useful_lane_frac": round(valu_prof / valu_peak * lane_util, 4),
-                         "frac_note": "frac = counters and duration of the SAME profiled launches (recomputable from profiles/" + PMC_FILE + "); frac_with_this_runs_ray_rate = the profiled issue quad-cycles "
+                         "frac_note": "frac = counters and duration of the SAME profiled launches at THEIR clock (GRBM_GUI_ACTIVE / duration: the chip lowers its clock under this kernel, differently from box to box; recomputable from profiles/" + PMC_FILE + "); "
+                                      "frac_at_2400_MHz / this_runs_rate_at_2400_MHz = the same issue quad-cycles against the roof at the 2.4 GHz peak clock; frac_with_this_runs_ray_rate = the profiled issue quad-cycles "
                                       "per ray x THIS run's ray rate (the views and the clock differ between runs); useful_lane_frac = frac x SIMD lane utilisation: the share of the VALU "
                                       "LANE-cycles that did work; pure instruction streams top out at 0.88 (v_fma_f32, dual issue) ... 0.94-0.97 (4- and 8-cycle classes): profiles/r3_counter_calibration.json",
                          "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "issue_quads_per_ray": round(quads_per_ray, 1),
