@@ -263,8 +263,9 @@ IRIS_API int iris_denoise(const float *normal, const float *position, const uint
 IRIS_API int64_t iris_ngp_n_params(void);
 IRIS_API int iris_ngp_create(const float *params, int64_t n_params, double voxel_min, double voxel_max, int device, iris_ngp **out);
 /* forward(position): position (N,3) f32 world space -> albedo (N,3), roughness (N) in [0.02,1], metallic (N), all f32 device pointers.
- * The handle owns the feature buffer the two kernels of a call exchange (2^20 points x 128 B): calls on ONE handle must be ordered on one stream
- * (or by events); different handles are independent. */
+ * Outputs lie on the HALF grid as the reference's do (model/brdf.py:255: the network's half output -> sigmoid -> half -> .float(); roughness * 0.98 + 0.02
+ * in f32 afterwards).  The handle owns the feature buffer the two kernels of a call exchange (2^20 points x 128 B); calls on ONE handle from different
+ * streams or host threads are serialised by the library (a device-side event wait, a host mutex); different handles are independent. */
 IRIS_API int iris_ngp_forward(const iris_ngp *, const float *position, int64_t N, float *albedo, float *roughness, float *metallic, iris_stream_t);
 IRIS_API void iris_ngp_destroy(iris_ngp *);
 

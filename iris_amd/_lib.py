@@ -128,6 +128,22 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def device_index(device):
+    """The HIP device ordinal a torch device names: `torch.device('cuda')` (no index) is torch's CURRENT device on this rank, not device 0 -- one process per
+    GPU sets it once (torch.cuda.set_device(LOCAL_RANK)) and then passes index-less devices around."""
+    import torch
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise IrisError(f"{device}: the HIP path needs a GPU device (there is no CPU fallback)")
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def build_id():
+    """What identifies the ARITHMETIC of the loaded library for a resumable run: its version string, the compiler flags embedded in it and the hash of the
+    kernel sources it was built from (a sampler or traversal change alters bits: maps of two builds must not be mixed by --resume)."""
+    return lib().iris_version().decode() + "|" + lib().iris_debug_build_flags().decode() + "|" + source_hash()
+
+
 def debug_set(key, value):
     """iris_debug_set (include/iris_hip_debug.h): process-wide tuning option; value < 0 restores the default."""
     check(lib().iris_debug_set(key.encode(), int(value)))

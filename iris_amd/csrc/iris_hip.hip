@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -231,10 +232,12 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     }
     iris_scene* s = new iris_scene();
     s->device = device;
-    HIP_TRY(hipMalloc(&s->d_nodes, nodes.size() * 4));
-    HIP_TRY(hipMalloc(&s->d_tris, tris.size() * 4));
-    HIP_TRY(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_tris, tris.data(), tris.size() * 4, hipMemcpyHostToDevice));
+    if (hipMalloc(&s->d_nodes, nodes.size() * 4) != hipSuccess || hipMalloc(&s->d_tris, tris.size() * 4) != hipSuccess ||
+        hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->d_tris, tris.data(), tris.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(s->d_nodes); (void)hipFree(s->d_tris); delete s;
+        return fail(IRIS_ERR_HIP, "iris_scene_create: device allocation / upload failed");
+    }
     s->dev.nodes = (const float4*)s->d_nodes;
     s->dev.tris = (const float4*)s->d_tris;
     s->dev.n_nodes = (int)nn;
@@ -344,6 +347,12 @@ struct iris_ngp {
     void* d_feat = nullptr;     // [32 levels][kChunk] half2: the encoded features of one chunk of points
     float vmin = 0.f, den = 1.f;
     uint64_t n_entries = 0;
+    // d_feat is the handle's ONE scratch buffer: forwards of one handle are serialised on the device -- a call on another stream than the previous call's first
+    // waits (on the device, not the host) for the event that call recorded behind its last kernel.  Host threads are serialised by the mutex.
+    mutable std::mutex mu;
+    mutable hipEvent_t last_use = nullptr;
+    mutable hipStream_t last_stream = nullptr;
+    mutable bool used = false;
 };
 constexpr int kNgpChunk = 1 << 20;       // points per encode / MLP launch pair: 128 MiB of features
 static uint64_t ngp_levels(NgpLevels& lv) {
@@ -372,6 +381,7 @@ extern "C" IRIS_API int64_t iris_ngp_n_params(void) {
 extern "C" IRIS_API int iris_ngp_create(const float* params, int64_t n_params, double voxel_min, double voxel_max, int device, iris_ngp** out) {
     API_BEGIN
     if (!out || !params) return fail(IRIS_ERR_ARG, "iris_ngp_create: bad arguments");
+    HIP_TRY(hipSetDevice(device));              // (before anything is allocated: an invalid device leaves nothing behind)
     iris_ngp* g = new iris_ngp();
     g->device = device;
     g->n_entries = ngp_levels(g->lv);
@@ -379,13 +389,13 @@ extern "C" IRIS_API int iris_ngp_create(const float* params, int64_t n_params, d
         delete g;
         return fail(IRIS_ERR_ARG, "iris_ngp_create: mlp.params has " + std::to_string(n_params) + " entries, the NGPBRDF configuration has " + std::to_string(iris_ngp_n_params()));
     }
-    HIP_TRY(hipSetDevice(device));
     std::vector<uint16_t> h((size_t)n_params);
     for (int64_t i = 0; i < n_params; ++i) h[(size_t)i] = f32_to_f16_bits(params[i]);
-    auto cleanup = [&](const char* msg) { (void)hipFree(g->d_grid); (void)hipFree(g->d_w); (void)hipFree(g->d_feat); delete g; return fail(IRIS_ERR_HIP, msg); };
+    auto cleanup = [&](const char* msg) { (void)hipFree(g->d_grid); (void)hipFree(g->d_w); (void)hipFree(g->d_feat); if (g->last_use) (void)hipEventDestroy(g->last_use); delete g; return fail(IRIS_ERR_HIP, msg); };
     if (hipMalloc(&g->d_w, (size_t)kNgpMlpParams * 2) != hipSuccess || hipMalloc(&g->d_grid, (size_t)g->n_entries * 4) != hipSuccess ||
         hipMalloc(&g->d_feat, (size_t)kNgpLevels * kNgpChunk * 4) != hipSuccess)
         return cleanup("iris_ngp_create: out of device memory");
+    if (hipEventCreateWithFlags(&g->last_use, hipEventDisableTiming) != hipSuccess) return cleanup("iris_ngp_create: hipEventCreate failed");
     if (hipMemcpy(g->d_w, h.data(), (size_t)kNgpMlpParams * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(g->d_grid, h.data() + kNgpMlpParams, (size_t)g->n_entries * 4, hipMemcpyHostToDevice) != hipSuccess)
         return cleanup("iris_ngp_create: upload failed");
@@ -400,6 +410,9 @@ extern "C" IRIS_API int iris_ngp_forward(const iris_ngp* g, const float* positio
     if (!g || N < 0 || (N > 0 && (!position || !albedo || !roughness || !metallic))) return fail(IRIS_ERR_ARG, "iris_ngp_forward: bad arguments");
     HIP_TRY(hipSetDevice(g->device));
     hipStream_t st = (hipStream_t)stream;
+    if (N == 0) return IRIS_OK;
+    std::lock_guard<std::mutex> lock(g->mu);
+    if (g->used && g->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, g->last_use, 0));      // the previous forward of this handle still owns d_feat
     NgpArgs a{};
     a.lv = g->lv; a.grid = (const uint32_t*)g->d_grid; a.w = (const _Float16*)g->d_w; a.pos = position; a.feat = (uint32_t*)g->d_feat;
     a.albedo = albedo; a.rough = roughness; a.metal = metallic; a.n_chunk = kNgpChunk; a.vmin = g->vmin; a.den = g->den;
@@ -410,6 +423,8 @@ extern "C" IRIS_API int iris_ngp_forward(const iris_ngp* g, const float* positio
         hipLaunchKernelGGL(ngp_mlp_kernel, dim3(std::min(std::max((tiles + 3) / 4, 1), 2048)), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->last_use, st));
+    g->last_stream = st; g->used = true;
     return IRIS_OK;
     API_END
 }
@@ -429,6 +444,7 @@ extern "C" IRIS_API int iris_debug_ngp_encode(const iris_ngp* g, const float* po
 extern "C" IRIS_API void iris_ngp_destroy(iris_ngp* g) {
     if (!g) return;
     (void)hipFree(g->d_grid); (void)hipFree(g->d_w); (void)hipFree(g->d_feat);
+    if (g->last_use) (void)hipEventDestroy(g->last_use);
     delete g;
 }
 

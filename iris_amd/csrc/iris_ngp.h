@@ -41,6 +41,7 @@ typedef _Float16 iris_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 iris_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 iris_h2v __attribute__((ext_vector_type(2)));
 typedef float iris_f16v __attribute__((ext_vector_type(16)));
+typedef uint32_t ngp_u2a __attribute__((ext_vector_type(2), aligned(4)));     // two adjacent table entries, 4-byte aligned
 
 // tiny-cuda-nn grid.h, kernel_grid, restated: position -> cell + weights, 8 corners, dense index while it fits the table, coherent prime hash otherwise
 __global__ __launch_bounds__(256) void ngp_encode_kernel(NgpArgs a) {
@@ -83,8 +84,10 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(NgpArgs a) {
         else { const uint32_t k = g1 * stride1 + g2 * stride2; ia = cell[0] + k; ib = cell[0] + 1u + k; }
         ia %= size; ib %= size;
         uint32_t ra, rb;
-        if (ib == ia + 1u) { const uint2 v = *reinterpret_cast<const uint2*>(table + ia); ra = v.x; rb = v.y; }
-        else if (ia == ib + 1u) { const uint2 v = *reinterpret_cast<const uint2*>(table + ib); ra = v.y; rb = v.x; }
+        // (the pair's base is an ODD entry about half the time on dense levels: the 8-byte load goes through a vector type declared 4-byte aligned -- gfx950
+        //  global memory runs in unaligned-access mode, so it is still ONE global_load_dwordx2, and no C++ alignment rule is broken)
+        if (ib == ia + 1u) { const ngp_u2a v = *reinterpret_cast<const ngp_u2a*>(table + ia); ra = v.x; rb = v.y; }
+        else if (ia == ib + 1u) { const ngp_u2a v = *reinterpret_cast<const ngp_u2a*>(table + ib); ra = v.y; rb = v.x; }
         else { ra = table[ia]; rb = table[ib]; }
 #pragma unroll
         for (int xx = 0; xx < 2; ++xx) {
@@ -107,6 +110,9 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(NgpArgs a) {
 }
 
 __device__ __forceinline__ float ngp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The reference's output stage (model/brdf.py:255): tiny-cuda-nn hands back HALF, `.sigmoid()` is taken on that half tensor (torch: f32 arithmetic, ONE rounding
+// to half) and only then `.float()` -- every albedo / metallic value, and the roughness before `* 0.98 + 0.02`, lies on the half grid.
+__device__ __forceinline__ float ngp_out(float acc) { return (float)(_Float16)ngp_sigmoid((float)(_Float16)acc); }
 
 // relu + f32 -> f16 of 8 accumulator registers: the B fragment of the next layer's k-step
 __device__ __forceinline__ iris_h8 ngp_pack_relu(const iris_f16v& acc, int s) {
@@ -198,11 +204,11 @@ __global__ __launch_bounds__(256) void ngp_mlp_kernel(NgpArgs a) {
         if (pv) {
             const int64_t g = a.n0 + pt;
             if (h == 0) {
-                // model/brdf.py:255-260: sigmoid; albedo = [..., :3], roughness = [..., 3:4] * 0.98 + 0.02
-                a.albedo[g * 3] = ngp_sigmoid(acc3[0]); a.albedo[g * 3 + 1] = ngp_sigmoid(acc3[1]); a.albedo[g * 3 + 2] = ngp_sigmoid(acc3[2]);
-                a.rough[g] = ngp_sigmoid(acc3[3]) * 0.98f + 0.02f;
+                // model/brdf.py:255-260: half -> sigmoid -> half -> float; albedo = [..., :3], roughness = [..., 3:4] * 0.98 + 0.02
+                a.albedo[g * 3] = ngp_out(acc3[0]); a.albedo[g * 3 + 1] = ngp_out(acc3[1]); a.albedo[g * 3 + 2] = ngp_out(acc3[2]);
+                a.rough[g] = ngp_out(acc3[3]) * 0.98f + 0.02f;          // (in f32, after .float(): model/brdf.py:258)
             } else {
-                a.metal[g] = ngp_sigmoid(acc3[0]);
+                a.metal[g] = ngp_out(acc3[0]);
             }
         }
     }

@@ -165,7 +165,7 @@ class NGPBRDF(BaseBRDF):
         if self._h is None or self._h_key != key:
             self._free()
             host = p.detach().to("cpu", torch.float32).contiguous()
-            idx = device.index if device.index is not None else torch.cuda.current_device()
+            idx = L.device_index(device)
             h = C.c_void_p()
             L.check(L.lib().iris_ngp_create(C.c_void_p(host.data_ptr()), host.numel(), self.voxel_min, self.voxel_max, idx, C.byref(h)))
             self._h, self._h_key = h, key
@@ -182,6 +182,12 @@ class NGPBRDF(BaseBRDF):
 
     def __del__(self):
         self._free()
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the native handle belongs to THIS object (a raw pointer: a copy would free it twice); the copy builds its own on first use"""
+        state = self.__dict__.copy()
+        state["_h"], state["_h_key"] = None, None
+        return state
 
     def forward(self, position):
         """position Bx3 (world space) -> {'albedo': Bx3, 'roughness': Bx1 in [0.02, 1], 'metallic': Bx1}  (model/brdf.py:243-260)"""

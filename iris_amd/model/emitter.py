@@ -64,7 +64,7 @@ class SLFEmitter(nn.Module):
             L.check(L.lib().iris_emitter_create(ie.ctypes.data_as(C.c_void_p), ie.shape[0], rad.ctypes.data_as(C.c_void_p), rad.shape[0],
                                                 area.ctypes.data_as(C.c_void_p), area.shape[0],
                                                 verts.ctypes.data_as(C.c_void_p) if has_v else None, cdf.ctypes.data_as(C.c_void_p) if has_v else None,
-                                                device.index or 0, C.byref(h)))
+                                                L.device_index(device), C.byref(h)))
             self._h, self._h_device, self._struct_ver = h, device, struct
             self._rad_version = self._ver(self.radiance)
         elif self._rad_version != self._ver(self.radiance):

@@ -184,8 +184,9 @@ def main(argv=None):
         st = os.stat(path)
         return (os.path.abspath(path), st.st_size, st.st_mtime_ns)
     # run_key: everything that determines the refined maps -- the arguments AND the identity of every input file (mesh, SLF, emitters, cameras, material
-    # checkpoint: a changed file under an unchanged path is a different run)
-    run_key = hashlib.sha256(repr((args.material, stamp(args.ckpt), stamp(mesh_path), stamp(args.slf_path), stamp(args.emitter_path), stamp(args.cameras),
+    # checkpoint: a changed file under an unchanged path is a different run) AND the build of the kernels (a sampler / traversal change alters bits: a resumed
+    # run must not mix maps of two arithmetic versions)
+    run_key = hashlib.sha256(repr((L.build_id(), args.material, stamp(args.ckpt), stamp(mesh_path), stamp(args.slf_path), stamp(args.emitter_path), stamp(args.cameras),
                                    args.dataset, os.path.abspath(args.scene), args.spp_diffuse, args.spp_specular, args.indir_depth, args.seed, args.res_scale,
                                    args.denoise, tuple(img_hw))).encode()).hexdigest()[:16]
 

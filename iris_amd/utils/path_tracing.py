@@ -27,10 +27,10 @@ class Scene:
         h = C.c_void_p()
         if int(layout) == L.BVH_DEFAULT:
             L.check(L.lib().iris_scene_create(v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0],
-                                              self.device.index or 0, C.byref(h)))
+                                              L.device_index(self.device), C.byref(h)))
         else:   # explicit node layout: diagnostics entry point (A/B baseline)
             L.check(L.lib().iris_debug_scene_create(v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0],
-                                                    self.device.index or 0, int(layout), C.byref(h)))
+                                                    L.device_index(self.device), int(layout), C.byref(h)))
         self._h = h
 
     @property

@@ -16,8 +16,9 @@ section 3; tiny-cuda-nn's `grid.h` / `fully_fused_mlp.cu` as documented there):
     64x64, 64x64, 16x64 (5 outputs padded to 16), computed in half
   * the reference feeds `position * 2 - 1` with position normalised to [0, 1] (model/brdf.py:252-254), i.e. inputs in [-1, 1]; the library
     does not clamp, negative cells wrap around in uint32 -- restated as is
-  * outputs: sigmoid of the first 5 -> albedo (3), roughness * 0.98 + 0.02, metallic, as float32 (the library hands back half and the reference
-    takes the sigmoid in half; here the f32 accumulators go through the sigmoid unrounded -- in the restatement and in the HIP path alike)
+  * outputs (model/brdf.py:255-260): the library hands back HALF; `.sigmoid()` runs on that half tensor (torch: f32 arithmetic, one rounding to half);
+    `.float()` afterwards -> albedo (3), roughness * 0.98 + 0.02 (in f32), metallic.  Restated as is: accumulators -> half -> sigmoid -> half -> float,
+    so every albedo / metallic value (and the roughness before its affine map) lies on the half grid, as the reference's do
 
 The HIP path (iris_amd/csrc/iris_ngp.h) is compared with THIS restatement (tests/test_ngp.py); it accumulates the MLP in f32 on the matrix cores
 where tiny-cuda-nn's fully fused kernel accumulates in half, so the bar is a tolerance (written in the test), not bit-exactness."""
@@ -115,5 +116,6 @@ def forward(params, position, voxel_min, voxel_max):
     """NGPBRDF.forward (model/brdf.py:243-260): position (B,3) world space -> {'albedo' (B,3), 'roughness' (B,1), 'metallic' (B,1)} float32."""
     pos = (position.to(torch.float32) - np.float32(voxel_min)) / np.float32(float(voxel_max) - float(voxel_min))       # python floats: the difference is taken in double
     x = pos * np.float32(2.0) - np.float32(1.0)
-    mat = torch.sigmoid(mlp(params, encode(params, x)).to(torch.float32))
+    out_half = mlp(params, encode(params, x)).to(torch.float16)                                     # what tcnn returns
+    mat = torch.sigmoid(out_half.to(torch.float32)).to(torch.float16).to(torch.float32)              # half sigmoid = f32 arithmetic + one rounding; then .float()
     return {"albedo": mat[:, :3].contiguous(), "roughness": mat[:, 3:4] * np.float32(0.98) + np.float32(0.02), "metallic": mat[:, 4:5].contiguous()}

@@ -86,3 +86,19 @@ def test_voxel_slf_built_on_the_device_and_rebound_buffers(dev):
     for k in range(6):                              # rebinding in a loop: freed addresses come back, versions restart at 0
         b.radiance = b.radiance / 2.0
         assert torch.equal(b(x)["rgb"], a(x)["rgb"] / 2.0 ** (k + 1))
+
+
+def test_index_less_device_is_the_current_device(dev, room_setup):
+    """`torch.device('cuda')` names torch's CURRENT device, not device 0 (one process per GPU passes index-less devices around after set_device):
+    Scene, SLFEmitter and NGPBRDF built with it work and give the bits the explicit index gives."""
+    from iris_amd import bake_shading as bs
+    from iris_amd.utils.path_tracing import Scene
+    s = room_setup
+    cur = torch.device("cuda")
+    sc = Scene(s["room"]["vertices"], s["room"]["faces"], device=cur)
+    P = 256
+    pos, nrm = T(s["pos"][:P], dev), T(s["nrm"][:P], dev)
+    base = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 64, seed=5)
+    s["em"].refresh()
+    s["em"].handle(cur)                                   # tables built for the index-less device
+    assert torch.equal(bs.bake_diffuse(sc, s["em"], pos.to(cur), nrm.to(cur), 64, seed=5), base)

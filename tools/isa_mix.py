@@ -27,7 +27,10 @@ def main():
     src = os.path.join(REPO, "iris_amd", "csrc", "iris_hip.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("isa_flags", os.path.join(REPO, "tools", "isa_flags.py")); fl = importlib.util.module_from_spec(spec); spec.loader.exec_module(fl)
+        hipcc, arch, flags = fl.makefile_flags()                # the flags of the SHIPPED library (iris_amd/csrc/Makefile), not a copy of them
+        cmd = [hipcc, "--offload-arch=" + arch] + flags + [
                "-I" + os.path.join(REPO, "include"), "-S", "--cuda-device-only", "-o", out, src] + args.extra.split()
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         lines = open(out).read().splitlines()

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Where a kernel's scratch traffic and lane moves sit: counts scratch_load / scratch_store / v_readlane / v_writelane by LLVM loop depth
 (tile loop = 1, trace_stream's round loop = 2, node / leaf phase loops = 3).   python tools/isa_spills.py [--kernel bake_view_kernelILi3] [--extra "-D..."]"""
-import argparse, collections, os, re, subprocess, tempfile
+import argparse, collections, os, re, shlex, subprocess, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+import importlib.util
+_spec = importlib.util.spec_from_file_location("isa_flags", os.path.join(REPO, "tools", "isa_flags.py")); _fl = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_fl)
+makefile_flags = _fl.makefile_flags
 ap = argparse.ArgumentParser(); ap.add_argument("--kernel", default="bake_view_kernelILi3"); ap.add_argument("--extra", default=""); ap.add_argument("--dump", default="")
 a = ap.parse_args()
 with tempfile.TemporaryDirectory() as tmp:
     out = a.dump or os.path.join(tmp, "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I" + os.path.join(REPO, "include"),
+    hipcc, arch, flags = makefile_flags()
+    subprocess.check_call([hipcc, "--offload-arch=" + arch] + flags + ["-I" + os.path.join(REPO, "include"),
                            "-S", "--cuda-device-only", "-o", out, os.path.join(REPO, "iris_amd", "csrc", "iris_hip.hip")] + a.extra.split(), stderr=subprocess.DEVNULL)
     lines = open(out).read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4iris\d+" + re.escape(a.kernel) + r".*:\s*(;.*)?$", l))
