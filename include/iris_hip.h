@@ -200,7 +200,10 @@ IRIS_API int iris_pt_brdf_trace(const iris_scene *, const float *pos, const floa
                        const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *wi,
                        float *pdf, float *weight, float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid,
                        int lobe, float lobe_roughness, iris_stream_t);
-/* :394-404  eval_emitter(..., mat_next.roughness, 0.0) + geometry term + MIS -> term2 = coef2 * radiance[e2] + const2 */
+/* :394-404  eval_emitter(..., mat_next.roughness, 0.0) + geometry term + MIS -> term2 = coef2 * radiance[e2] + const2.
+ * roughness_next may be NULL: "every roughness exceeds trace_roughness" -- the only use of mat_next in the reference's path_tracing_single is the test
+ * roughness > trace_roughness = 0.0 (model/emitter.py:209), and NGPBRDF's roughness is sigmoid * 0.98 + 0.02 >= 0.02 (model/brdf.py:258): a caller that knows its
+ * material network's lower bound skips the second network evaluation (same outputs, bit for bit). */
 IRIS_API int iris_pt_brdf_finish(const iris_emitter *, const iris_slf *, const float *pos, const float *pos_next, const float *nrm_next,
                         const float *wi, const int64_t *tri_next, const float *roughness_next, const float *pdf, const float *weight,
                         int64_t N, float *coef2, float *const2, int32_t *e2, uint8_t *valid_next /*nullable*/, float trace_roughness,

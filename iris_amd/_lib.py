@@ -144,6 +144,42 @@ def build_id():
     return lib().iris_version().decode() + "|" + lib().iris_debug_build_flags().decode() + "|" + source_hash()
 
 
+class StageTimer:
+    """Diagnostics (bench.py extras, tools/bench_pt_single.py): HIP events around the stages of a multi-kernel call.  `with L.StageTimer() as t:` makes every
+    `L.mark(name)` inside record an event on the stream that is current THERE; `t.ms()` -> {stage: milliseconds between its mark and the previous mark on the
+    same stream} (stages on different streams overlap: the figures do not add up to the wall time).  Not active (no events, no cost) otherwise."""
+    active = None
+
+    def __enter__(self):
+        self.events = []          # (stream id, name, event)
+        StageTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        StageTimer.active = None
+
+    def ms(self):
+        import torch
+        torch.cuda.synchronize()
+        out, last = {}, {}
+        for sid, name, ev in self.events:
+            if sid in last and name is not None:
+                out[name] = out.get(name, 0.0) + last[sid].elapsed_time(ev)
+            last[sid] = ev
+        return out
+
+
+def mark(name=None):
+    """StageTimer: end of stage `name` (None: start of a sequence) on the current stream"""
+    t = StageTimer.active
+    if t is not None:
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream()
+        ev.record(st)
+        t.events.append((st.cuda_stream, name, ev))
+
+
 def debug_set(key, value):
     """iris_debug_set (include/iris_hip_debug.h): process-wide tuning option; value < 0 restores the default."""
     check(lib().iris_debug_set(key.encode(), int(value)))

@@ -1231,7 +1231,7 @@ extern "C" IRIS_API int iris_pt_brdf_finish(const iris_emitter* e, const iris_sl
                                    const float* wi, const int64_t* tri_next, const float* roughness_next, const float* pdf, const float* weight,
                                    int64_t N, float* coef2, float* const2, int32_t* e2, uint8_t* valid_next, float trace_roughness, float g_eps,
                                    iris_stream_t stream) {
-    if (!e || !slf || N < 0 || (N > 0 && (!pos || !pos_next || !nrm_next || !wi || !tri_next || !roughness_next || !pdf || !weight || !coef2 || !const2 || !e2)))
+    if (!e || !slf || N < 0 || (N > 0 && (!pos || !pos_next || !nrm_next || !wi || !tri_next || !pdf || !weight || !coef2 || !const2 || !e2)))      // (roughness_next may be NULL: see iris_hip.h)
         return fail(IRIS_ERR_ARG, "iris_pt_brdf_finish: bad arguments");
     if (N == 0) return IRIS_OK;
     PtArgs a{};

@@ -302,7 +302,7 @@ __global__ void pt_brdf_finish_kernel(PtArgs a) {
         if (is_area) emit_pdf = a.em.emitter_pdf / fmaxf(a.em.area[ord], 1e-12f);
         bool valid_next = (!is_area) && vis;
         f3 slf = mk3(0.f, 0.f, 0.f);
-        if ((!is_area) && vis && a.rough_next[i] > a.trace_rough) {
+        if ((!is_area) && vis && (!a.rough_next || a.rough_next[i] > a.trace_rough)) {       // (rough_next NULL: the caller KNOWS that every roughness exceeds trace_roughness)
             slf = slf_forward(a.slf, pn);
             if ((slf.x + slf.y) + slf.z > 0.f) valid_next = false;
         }

@@ -152,6 +152,11 @@ class NGPBRDF(BaseBRDF):
     kernels (level-major gathers; the perceptron on the matrix cores, iris_amd/csrc/iris_ngp.h).  tiny-cuda-nn is third party and CUDA only: its published
     algorithm is implemented, parity unpinned (oracle/ngp_torch.py).  No backward pass: training the material network is train_brdf_crf's job (out of scope)."""
 
+    # roughness = sigmoid(.) * 0.98 + 0.02 (model/brdf.py:258): never below 0.02 for finite network outputs.  path_tracing_single uses its SECOND evaluation of the
+    # network (mat_next, utils/path_tracing.py:392) only for the test roughness > trace_roughness = 0.0 (model/emitter.py:209), whose outcome this bound decides:
+    # iris_amd.utils.path_tracing skips that evaluation when the network declares a bound above trace_roughness (same outputs, bit for bit).
+    roughness_min = 0.02
+
     def __init__(self, voxel_min, voxel_max):
         super().__init__()
         self.voxel_min, self.voxel_max = float(voxel_min), float(voxel_max)

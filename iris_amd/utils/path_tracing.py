@@ -4,6 +4,7 @@ The reference wraps Mitsuba's OptiX closest hit; here the scene is a BVH built o
 ``iris_scene_create`` and traversed by hand-written gfx950 kernels.
 """
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -203,7 +204,7 @@ class _PtAccumulate(torch.autograd.Function):
         return (g.to(rad_dev),) + (None,) * 9
 
 
-def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, uniforms=None, compact=None):
+def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, uniforms=None, compact=None, skip_unused_material=True):
     """Path trace the scene with one bounce and power-2 MIS (utils/path_tracing.py:320-407).
 
     Args as the reference: rays_o, rays_d, dx_du, dy_dv Bx3; spp samples per pixel.  material_net(position) returns
@@ -214,9 +215,13 @@ def path_tracing_single(scene, emitter_net, material_net, rays_o, rays_d, dx_du,
     not continue (missed / emitter primary hits: a per-cent of the rays) -- the same per-path arithmetic and the same sum order, no host
     synchronisation anywhere in the call, which is what a training loop of 262 144-ray calls is bound by; None = False when the draws are this
     function's own (uniforms is None), True otherwise.
+    skip_unused_material: the reference evaluates material_net a SECOND time at the sampled hits (:392) and uses the result only for the test
+    roughness > trace_roughness = 0.0 (model/emitter.py:209).  A network that declares a lower bound of its roughness above that (`roughness_min`: NGPBRDF's
+    sigmoid * 0.98 + 0.02 >= 0.02) decides the test without being evaluated: the call is skipped, the outputs are the same bit for bit
+    (tests/test_pt_single.py); False = evaluate it as the reference does.  Any other callable is always evaluated.
     Returns L Bx3, differentiable with respect to emitter_net.radiance.
     """
-    return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, 0, uniforms, compact=compact)
+    return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, 0, uniforms, compact=compact, skip_unused_material=skip_unused_material)
 
 
 def path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms=None):
@@ -229,7 +234,20 @@ def path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv,
     return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, int(indir_depth), uniforms, full=True)
 
 
-def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, full=False, compact=None):
+_CONST = {}
+
+
+def _const_indices(n, dev):
+    """arange(n) and full(n, -1) as int32 on `dev`, built once per size (path_of of the un-compacted mode: one kernel per call instead of three)"""
+    key = (n, str(dev))
+    if key not in _CONST:
+        if len(_CONST) > 8:
+            _CONST.clear()
+        _CONST[key] = (torch.arange(n, device=dev, dtype=torch.int32), torch.full((n,), -1, device=dev, dtype=torch.int32))
+    return _CONST[key]
+
+
+def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, full=False, compact=None, skip_unused_material=True):
     rays_o = L.require_gpu(rays_o, torch.float32, "rays_o").reshape(-1, 3)
     rays_d = L.require_gpu(rays_d, torch.float32, "rays_d").reshape(-1, 3)
     dx_du = L.require_gpu(dx_du, torch.float32, "dx_du").reshape(-1, 3)
@@ -241,9 +259,25 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
     if full and not compact:
         raise L.IrisError("path_tracing: the continuation (trace_indirect) compacts its paths; compact=False is for path_tracing_single")
     u = list(uniforms) if uniforms is not None else None
-    nxt = (lambda *shape: L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(*shape)) if u is not None else (lambda *shape: torch.rand(*shape, device=dev))
+    trace_rough = 0.6 if full else 0.0
+    rough_min = getattr(material_net, "roughness_min", None)
+    skip_next = bool(skip_unused_material) and rough_min is not None and float(rough_min) > trace_rough     # (see path_tracing_single's docstring)
+    if u is not None:
+        nxt = lambda *shape: L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(*shape)             # noqa: E731
+    elif not compact:
+        # the function's own draws, all path counts known up front (N = B * spp): ONE generator launch for the five tensors of the call (8 N floats) instead of five
+        pool, off = torch.rand(8 * B * spp, device=dev), [0]
+
+        def nxt(*shape):
+            n = math.prod(shape)
+            t = pool[off[0]:off[0] + n].reshape(*shape)
+            off[0] += n
+            return t
+    else:
+        nxt = lambda *shape: torch.rand(*shape, device=dev)                                               # noqa: E731
 
     with torch.cuda.device(dev):
+        L.mark()
         dudv = nxt(2, B, spp)
         wi = torch.empty(B * spp, 3, device=dev)
         L.check(lib.iris_pt_jitter(L.ptr(rays_d), L.ptr(dx_du), L.ptr(dy_dv), L.ptr(dudv), B, spp, L.ptr(wi), L.stream()))
@@ -268,14 +302,16 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
             # every path stays at its ray's index; the ones that do not continue keep path_of = -1 and are ignored by the accumulation (their stage
             # outputs are computed on the zeros ray_intersect returns for a miss, or on the emitter hit, and never read)
             N = B * spp
-            path_of = torch.where(valid_next, torch.arange(N, device=dev, dtype=torch.int32), torch.full((N,), -1, device=dev, dtype=torch.int32))
+            path_of = torch.where(valid_next, *_const_indices(N, dev))
             wo = -wi
 
+        L.mark("jitter + primary hit")
         mat = material_net(position)
         albedo = mat["albedo"].detach().to(torch.float32).reshape(-1, 3).contiguous()
         rough = mat["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
         metal = mat["metallic"].detach().to(torch.float32).reshape(-1).contiguous()
 
+        L.mark("material (primary hits)")
         # direct illumination: emitter sampling + MIS (:357-382).  Independent of the BRDF-sampling branch below: launched on a side stream, so that
         # its visibility rays run beside the (longer) BRDF rays -- at 262 144 paths per call either kernel alone leaves most of the chip idle
         s1, s2 = nxt(N), nxt(N, 2)
@@ -284,8 +320,10 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         fork = torch.cuda.Event(); fork.record(main)
         with torch.cuda.stream(side):
             side.wait_event(fork)
+            L.mark()
             L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
                                     L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 0.0 if full else 1e-6, L.stream()))
+            L.mark("nee (side stream)")
             join = torch.cuda.Event(); join.record(side)
         for t_side in (position, normal, wo, albedo, rough, metal, s1, s2, coef1, e1):
             t_side.record_stream(side)     # an exception in a main-stream stage below must not hand these blocks back to the main-stream pool while the side kernel still reads them
@@ -296,20 +334,28 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         tri_n = torch.empty(N, device=dev, dtype=torch.int64); hit_n = torch.empty(N, device=dev, dtype=torch.bool)
         L.check(lib.iris_pt_brdf_trace(scene.handle, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1b), L.ptr(s2b), N,
                                        L.ptr(wi_b), L.ptr(pdf_b), L.ptr(w_b), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(tri_n), L.ptr(hit_n), 0, 0.0, L.stream()))
-        mat_next = material_net(pos_n)
-        rough_n = mat_next["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
+        L.mark("brdf sample + trace")
+        if skip_next:
+            rough_n = None           # every roughness of this network exceeds trace_roughness: the finish stage's test is decided (iris_hip.h)
+        else:
+            mat_next = material_net(pos_n)
+            rough_n = mat_next["roughness"].detach().to(torch.float32).reshape(-1).contiguous()
+        L.mark("material (sampled hits)")
         # eval_emitter at the sampled hit + MIS (:394-404)
         coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
         hit_valid = torch.empty(N, device=dev, dtype=torch.bool) if full else None
-        L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi_b), L.ptr(tri_n), L.ptr(rough_n), L.ptr(pdf_b), L.ptr(w_b), N,
-                                        L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(hit_valid) if full else None, 0.6 if full else 0.0, 1e-6, L.stream()))
+        L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi_b), L.ptr(tri_n), L.ptr(rough_n) if rough_n is not None else None,
+                                        L.ptr(pdf_b), L.ptr(w_b), N, L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(hit_valid) if full else None, trace_rough, 1e-6, L.stream()))
+        L.mark("finish")
         main.wait_event(join)              # (before anything frees or reads the tensors the side stream works on)
         if full and indir_depth > 0:
             keep = torch.nonzero(hit_valid, as_tuple=False).reshape(-1)
             L_indir = trace_indirect(scene, emitter_net, material_net, pos_n[keep].contiguous(), (-wi_b[keep]).contiguous(), nrm_n[keep].contiguous(), indir_depth,
                                      uniforms=u)                                  # (u: what is left of the recorded draws, or None)
             const2[keep] = const2[keep] + w_b[keep] * L_indir                     # rides on the constant term: no gradient, as in the reference
-    return _PtAccumulate.apply(radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp)
+    out = _PtAccumulate.apply(radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp)
+    L.mark("accumulate")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -57,12 +57,12 @@ def test_forced_process_group_of_one_runs_rccl():
         assert d["parity_check"]["bit_exact"] is True
 
 
-def _two_ranks(*extra, env_extra=None, expect_ok=True):
-    """--gpus 2 as a plain command starts its own two workers; with IRIS_BENCH_BACKEND=gloo they may share the one GPU of this box
+def _two_ranks(*extra, env_extra=None, expect_ok=True, n=2):
+    """--gpus N as a plain command starts its own N workers; with IRIS_BENCH_BACKEND=gloo they may share the one GPU of this box
     (a functional check of the N > 1 control flow -- never a measurement)."""
     import time
     env = dict(os.environ, IRIS_BENCH_BACKEND="gloo", **(env_extra or {}))
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "120", "--width", "160", "--spp", "32",
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--height", "120", "--width", "160", "--spp", "32",
            "--tris", "20000", "--slf-res", "64", "--views", "4", "--cpu-seconds", "0", "--no-extras", "--no-roofline"] + list(extra)
     t0 = time.time()
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
@@ -84,6 +84,20 @@ def test_two_ranks_on_one_gpu_line(collective):
     mg = d["multi_gpu"]
     assert mg["ranks_seen_by_all_reduce"] == 2 and mg["backend"] == "gloo" and len(mg["per_rank_ms_per_step"]) == 2 and mg["gather_ms"] is not None
     assert mg["gather_overlapped"] is True and mg["collective"] == collective and mg["gathered_image_matches_what_the_ranks_sent"] is True
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_on_one_gpu_line():
+    """BASELINE configs[3]'s rank count: `bench.py --gpus 8` starts eight workers (spawn_workers), they rendezvous, pass the barriers and the timed loop, send 15
+    stripes of 8 rows through the gather (seven ranks own two, the eighth one: padded send rows) and rank 0 prints the one line -- eight gloo ranks sharing this
+    box's GPU: functional evidence only, never a measurement."""
+    d, _ = _two_ranks("--gather", "gather", n=8)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen_by_all_reduce"] == 8 and mg["backend"] == "gloo" and len(mg["per_rank_ms_per_step"]) == 8
+    assert mg["collective"] == "gather" and mg["gathered_image_matches_what_the_ranks_sent"] is True
+    rays = 120 * 160 * 32 * 7
+    assert 0.5 * rays < d["config"]["rays_per_step"] <= rays                      # strong scaling: ONE view per step, whatever N
 
 
 @pytest.mark.timeout(900)

@@ -150,6 +150,62 @@ def test_hip_path_tracing_single_forward_backward(tmp_path, oracle_mod):
 
 
 @pytest.mark.gpu
+def test_skipping_the_unused_material_evaluation_changes_nothing(tmp_path):
+    """The reference evaluates the material network a second time at the sampled hits (utils/path_tracing.py:392) and uses only `roughness > trace_roughness = 0.0`
+    of it (model/emitter.py:209).  NGPBRDF's roughness is sigmoid * 0.98 + 0.02 >= 0.02, so path_tracing_single does not launch that evaluation
+    (skip_unused_material, the default): L and the gradient must be the bits of the literal evaluation order -- for the function's own draws (one fused
+    generator launch) and for recorded draws in the compacted mode; a callable without a declared bound is always evaluated."""
+    from iris_amd.model.brdf import NGPBRDF
+    from iris_amd.utils.path_tracing import path_tracing_single
+    dev = torch.device("cuda:0")
+    g, p, scene, em = _gpu_setup(tmp_path, dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
+    mat = StubMaterial()
+    net = NGPBRDF(float(g["voxel_min"]), float(g["voxel_max"]))
+    net.load_state_dict({"mlp.params": (torch.rand(net.mlp.params.numel(), generator=torch.Generator().manual_seed(2)) * 2 - 1) * 0.3})
+    assert net.roughness_min == 0.02
+    rays = [T(p[k]) for k in ("rays_o", "rays_d", "dx_du", "dy_dv")]
+    spp = 16
+    calls = []
+    orig = NGPBRDF.forward
+
+    def counting(self, position):
+        calls.append(position.shape[0])
+        out = orig(self, position)
+        assert float(out["roughness"].min()) >= 0.02               # the bound the skip relies on
+        return out
+    NGPBRDF.forward = counting
+    try:
+        res = {}
+        for skip in (True, False):
+            calls.clear()
+            em.radiance.grad = None
+            torch.manual_seed(5); torch.cuda.manual_seed(5)
+            L = path_tracing_single(scene, em, net, *rays, spp, skip_unused_material=skip)
+            L.square().sum().backward()
+            res[skip] = (L.detach().clone(), em.radiance.grad.clone(), len(calls))
+        assert res[True][2] == 1 and res[False][2] == 2
+        assert torch.equal(res[True][0], res[False][0])
+        assert rel_l2(res[True][1].cpu().numpy(), res[False][1].cpu().numpy()) <= 1e-6           # (the backward pass is a scatter of float atomics: equal up to summation order, skip or no skip)
+        assert float(res[True][0].abs().sum()) > 0 and float(res[True][1].abs().sum()) > 0
+        # recorded draws (the reference's compacted mode): the same
+        u = [T(p[f"u{k}"]) for k in range(5)]
+        La = path_tracing_single(scene, em, net, *rays, int(p["spp"]), uniforms=u, skip_unused_material=True)
+        Lb = path_tracing_single(scene, em, net, *rays, int(p["spp"]), uniforms=u, skip_unused_material=False)
+        assert torch.equal(La, Lb)
+        # a callable that declares nothing is evaluated twice whatever the flag
+        seen = []
+
+        def plain(position):
+            seen.append(1)
+            return mat(position)
+        path_tracing_single(scene, em, plain, *rays, spp, skip_unused_material=True)
+        assert len(seen) == 2
+    finally:
+        NGPBRDF.forward = orig
+
+
+@pytest.mark.gpu
 def test_training_step_replayed_as_hip_graph(tmp_path):
     """forward + backward of the un-compacted mode captured once as a HIP graph (torch.cuda.CUDAGraph) and replayed: every launch of the path
     is stream-ordered and allocates nothing outside torch's pool, so the replay gives what the eager step gives (the scatter-add of the

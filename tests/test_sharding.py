@@ -132,3 +132,51 @@ def test_forced_collective_at_world_one():
     assert q.get(timeout=100) is True
     p.join(timeout=30)
     assert p.exitcode == 0
+
+
+def _worker_1080p(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from iris_amd import sharding as sh
+        H, W, M = 1080, 1920, 1
+        ids = sh.local_pixel_ids(H, W, world, rank)
+        # map value = a function of (image pixel, channel) that is exact in f32 (ids < 2^21, x 3 + c < 2^23): whatever route a row takes, it is recognisable
+        local = (ids[None, :, None] * 3 + torch.arange(3)[None, None, :]).to(torch.float32) + 0.5
+        n_rows = ids.numel() // W
+        assert n_rows == (136 if rank < 7 else 128)                     # 135 stripes of 8 rows: ranks 0..6 own 17, rank 7 owns 16 -> its 8 padding rows travel too
+        ok = True
+        for mode in ("gather", "all_gather"):
+            ga = sh.MapGatherer(H, W, world, rank, M, "cpu", mode=mode)
+            assert ga.n_max == 136 * W and ga.n_local == n_rows * W
+            for k in range(2):                                           # buffers reused over "views"
+                full = ga(local + k)
+                if mode == "gather" and rank != 0:
+                    ok &= full is None
+                    continue
+                want = (torch.arange(H * W)[None, :, None] * 3 + torch.arange(3)[None, None, :]).to(torch.float32) + 0.5 + k
+                ok &= full is not None and torch.equal(full, want)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_at_the_real_stripe_geometry():
+    """BASELINE configs[3]'s collective at its real geometry, over gloo on the CPU (8 processes): a 1920 x 1080 map in 135 stripes of 8 rows -- seven ranks own 17
+    stripes, the eighth 16, so the padded rows of the send buffers go through a REAL 8-rank gather / all_gather and the permutation back to image order must
+    drop them.  Functional evidence for the N = 8 path (the build has one GPU; the driver's 8-GPU run decides the timing)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker_1080p, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {r: True for r in range(world)}
