@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "pmc_r4.json"
+PMC_FILE = "pmc_r5.json"
 N_SIMD, N_CU = 1024, 256
 
 

@@ -132,7 +132,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     WideBvh bvh = build_wide_bvh(verts, nv, faces, nf, 4, max_leaf, 2e-5f, tri_cost, presplit);
     if (bvh.tri_order.size() >= (size_t)(1 << 26) - 1) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^26 leaf records");
     if (3 * bvh.depth + 4 > kStackLds + kStackSpill) return fail(IRIS_ERR_BUILD, "iris_scene_create: BVH too deep for the traversal stack");
-    if (layout == IRIS_BVH4_Q8 && bvh.nodes.size() >= ((size_t)1 << 23)) return fail(IRIS_ERR_BUILD, "iris_scene_create: more than 2^23 BVH nodes (32-bit byte offsets into the eight octant copies)");
+    if (layout == IRIS_BVH4_Q8 && bvh.nodes.size() * kNodeBytes * 8 >= ((size_t)1 << 32)) return fail(IRIS_ERR_BUILD, "iris_scene_create: the eight octant copies of the node table exceed 4 GiB (32-bit byte offsets)");
 
     // ---- encode nodes ----
     const size_t nn = bvh.nodes.size();
@@ -145,7 +145,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
         if (w.child[s] >= 0) return (uint32_t)w.child[s];
         return kLeafBit | ((uint32_t)w.leaf_start[s] << 3) | (uint32_t)w.leaf_count[s];
     };
-    const int node_floats = layout == IRIS_BVH4_Q8 ? 16 : 32;
+    const int node_floats = layout == IRIS_BVH4_Q8 ? (int)kNodeBytes / 4 : 32;
     const int n_copies = layout == IRIS_BVH4_Q8 ? 8 : 1;       // Q8: one copy of the node table per ray octant (see below)
     std::vector<float> nodes(nn * node_floats * n_copies);
     for (size_t i = 0; i < nn; ++i) {
@@ -169,8 +169,10 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
             }
             uint32_t ebytes = 0;
             uint8_t q[6][4];   // planes lo_x lo_y lo_z hi_x hi_y hi_z
+            double ext_max = 0.0;
+            for (int k = 0; k < 3; ++k) ext_max = std::max(ext_max, (double)hi3[k] - (double)org[k]);
             for (int k = 0; k < 3; ++k) {
-                const double ext = (double)hi3[k] - (double)org[k];
+                const double ext = IRIS_NODE80 ? ext_max : (double)hi3[k] - (double)org[k];     // (80-B nodes: ONE plane scale per node, that of the longest axis)
                 int e = -126;
                 if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
                 while (std::ldexp(255.0, e) < ext) ++e;                       // 255 * 2^e must cover the extent
@@ -198,8 +200,24 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
             // node -- 105 MB for the bench scene next to 288 GB -- against ~30 vector instructions per visit.  Child references are node indices
             // (the same in every copy); a ray adds its copy's base offset (SceneDev::oct_stride).
             for (int o = 0; o < 8; ++o) {
-                float* po = nodes.data() + ((size_t)o * nn + i) * 16;
+                float* po = nodes.data() + ((size_t)o * nn + i) * node_floats;
                 po[0] = org[0]; po[1] = org[1]; po[2] = org[2];
+#if IRIS_NODE80
+                // {origin.xyz, scale} {ref[4]} {x planes of children 0..3} {y planes} {z planes}: a plane word = near byte | far byte << 16 (two f16 subnormals)
+                po[3] = std::ldexp(1.0f, (int)(ebytes & 0xffu) - 127 + 24);
+                for (int j = 0; j < 4; ++j) {
+                    const int sl = j < w.n ? (int)w.order[o][j] : j;
+                    const uint32_t ref = child_ref(w, sl);
+                    std::memcpy(&po[4 + j], &ref, 4);
+                    for (int k = 0; k < 3; ++k) {
+                        const bool neg = (o >> k) & 1;
+                        const uint32_t near_q = neg ? q[3 + k][sl] : q[k][sl], far_q = neg ? q[k][sl] : q[3 + k][sl];
+                        const uint32_t word = near_q | (far_q << 16);
+                        std::memcpy(&po[8 + 4 * k + j], &word, 4);
+                    }
+                }
+                continue;
+#endif
                 for (int k = 0; k < 3; ++k) po[3 + k] = std::ldexp(1.0f, (int)((ebytes >> (8 * k)) & 0xffu) - 127 + 24);
                 uint8_t qo[6][4];
                 for (int j = 0; j < 4; ++j) {
@@ -243,11 +261,11 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     s->dev.n_nodes = (int)nn;
     s->dev.n_tris = (int)nt;
     s->dev.layout = layout == IRIS_BVH4_Q8 ? kLayoutQ8 : kLayoutF32;
-    s->dev.oct_stride = layout == IRIS_BVH4_Q8 ? (uint32_t)(nn * 64) : 0u;
+    s->dev.oct_stride = layout == IRIS_BVH4_Q8 ? (uint32_t)(nn * kNodeBytes) : 0u;
     s->dev.phase_min = kPhaseMin;
     if (g_opt_phase_min >= 0) s->dev.phase_min = (int)g_opt_phase_min;  // iris_debug_set("phase_min") (results do not depend on it)
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
-    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? 64 : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth;
+    s->info.node_bytes = layout == IRIS_BVH4_Q8 ? (int)kNodeBytes : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth;
     s->info.sah_cost = bvh.sah_cost; s->info.n_leaf_records = (int32_t)nt;
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;

@@ -8,6 +8,16 @@ namespace iris {
 constexpr int kBlock = 256;          // threads per workgroup for every traversal kernel
 constexpr int kStackLds = 24;        // per-lane stack entries kept in LDS (24 KiB per workgroup)
 constexpr int kStackSpill = 72;      // rarely-touched overflow in scratch (correctness only)
+// Q8 node record.  IRIS_NODE80 = 0: 64 B, 8-bit planes four to a word (a visit isolates near / far byte pairs with 12 v_perm_b32).
+// IRIS_NODE80 = 1 (round 5): 80 B = {origin.xyz, scale} {ref[4]} {12 plane words}: every (axis, child) has its OWN word, near byte in the low half, far byte in the
+// high half, each zero-extended to 16 bits -- i.e. ALREADY the pair of f16 subnormals v_fma_mix_f32 reads: no v_perm_b32 in a visit (12 of its 91 vector
+// instructions, all of the 4-cycle class), five 16-B loads instead of four, ONE plane scale per node (the largest axis extent; 80 B = five loads exactly) --
+// tools/bvh_eval: +0.8 % node visits, +1.6 % triangle tests from the coarser planes on a node's short axes.
+#ifndef IRIS_NODE80
+#define IRIS_NODE80 0
+#endif
+constexpr uint32_t kNodeBytes = IRIS_NODE80 ? 80u : 64u;
+__device__ __forceinline__ uint32_t node_offset(uint32_t cur) { return IRIS_NODE80 ? cur * 80u : cur << 6; }
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
 
@@ -257,7 +267,26 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // The node table exists once per ray octant (iris_hip.hip): the copy a ray reads holds the children in ITS front-to-back order (the order of
         // the binary splits the node was collapsed from) and, per axis, the plane it meets first in the "near" bytes -- so a visit selects no planes
         // by the ray's signs and sorts nothing.  32-bit byte offset from the (scalar) table base: one shift-add per visit.
-        glb_u4v* n = (glb_u4v*)(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)((r.cur << 6) + r.oct_base));
+        glb_u4v* n = (glb_u4v*)(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(node_offset(r.cur) + r.oct_base));
+        typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
+#if IRIS_NODE80
+        iris_u4v hd = n[0], rf = n[1], px = n[2], py = n[3], pz = n[4];            // {origin.xyz, scale} {ref[4]} {x planes of children 0..3} {y planes} {z planes}
+        // (all five 16-B loads HERE: left alone hipcc narrows the plane loads to single words and sinks those of children 1..3 behind the test of child 0 --
+        //  dependent round trips inside a visit)
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+        r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
+        const float sc24 = __uint_as_float(hd.w);                                   // 2^(e+24), one per node
+        const float ax = sc24 * ix, ay = sc24 * iy, az = sc24 * iz;
+        const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
+        // a plane word IS the (near, far) pair of f16 subnormals q * 2^-24: v_fma_mix_f32 reads its halves directly
+#define IRIS_SLABQ(D, C)                                                                                                          \
+    {                                                                                                                             \
+        const iris_h2 hx = __builtin_bit_cast(iris_h2, (uint32_t)px[C]), hy = __builtin_bit_cast(iris_h2, (uint32_t)py[C]), hz = __builtin_bit_cast(iris_h2, (uint32_t)pz[C]);   /* (a prvalue: __builtin_bit_cast of the vector ELEMENT lvalue reads element 0 whatever the index -- hipcc 7.2) */ \
+        float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
+        float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
+        D = tf - tn;                                                                                                              \
+    }
+#else
         const iris_u4v hd = n[0], q1 = n[1], q2 = n[2], rf = n[3];
         r0 = rf.x; r1 = rf.y; r2 = rf.z; r3 = rf.w;
         // per-axis: t(q) = q * 2^e * idir + (origin * idir - o * idir); the node stores 2^(e+24) as a float (see below)
@@ -268,7 +297,6 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // child into the two halves of a register and v_fma_mix_f32 reads an f16 operand directly: 1 + 2 instructions per axis and child
         // instead of 2 conversions + 2 FMAs.  The node stores scale * 2^24, so q*2^-24 * (scale*2^24*idir) + b is the same real number,
         // rounded once by the FMA.
-        typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
 #define IRIS_PLANES(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
 #define IRIS_SLABQ(D, C)                                                                                                          \
     {                                                                                                                             \
@@ -277,10 +305,13 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
         D = tf - tn;                     /* sign clear: the child is hit (tn <= tf).  tn = tf gives +0; a NaN (inf - inf: tn = tf = inf) with a clear sign  */ \
     }                                    /* would only cost a wasted visit                                                                                */
+#endif
         float d0, d1, d2, d3;
         IRIS_SLABQ(d0, 0) IRIS_SLABQ(d1, 1) IRIS_SLABQ(d2, 2) IRIS_SLABQ(d3, 3)
 #undef IRIS_SLABQ
+#if !IRIS_NODE80
 #undef IRIS_PLANES
+#endif
         // Slots are in visiting order: the first child hit is next, the others wait on the stack, the farthest at the bottom.  The conditions are
         // taken from the SIGN BITS of the interval lengths with integer and / or (2-cycle dual-issue instructions; boolean algebra on compare results is
         // what hipcc turns into 0 / 1 registers, and fminf / fmaxf bring a canonicalising v_max x, x per operand): "child j is hit" = sign clear.
@@ -364,15 +395,36 @@ __device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r
     //  below back into v_perm_b32.  Issuing the load BEFORE the test, so that its latency runs under the compare / count / branch -- with a wait in the
     //  path not taken, whose registers must not be reused while it is in flight --: no gain, -0.2 %.)
     typedef uint32_t iris_u16v __attribute__((ext_vector_type(16)));
-    iris_u16v w;
+    typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
     const uint64_t base = reinterpret_cast<uint64_t>(sc.nodes);
     const uint32_t off_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)off0);    // (inside `if (off == off0)` hipcc substitutes the per-lane value for the uniform one)
-    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(base), "s"(off_s) : "memory");
     const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
+#if IRIS_NODE80
+    // 20 words: {origin.xyz, scale} {ref[4]} {x planes of children 0..3} {y planes} | {z planes}: one x16 and one x4 scalar load; a plane word is the (near, far)
+    // pair of f16 subnormals as it stands -- no byte isolation on the scalar ALU either
+    typedef uint32_t iris_u4s __attribute__((ext_vector_type(4)));
+    iris_u16v w; iris_u4s wz;
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %3 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w), "=&s"(wz) : "s"(base), "s"(off_s) : "memory");
+    uint32_t r0 = w[4], r1 = w[5], r2 = w[6], r3 = w[7];
+    const float sc24 = __uint_as_float(w[3]);
+    const float ax = sc24 * ix, ay = sc24 * iy, az = sc24 * iz;
+    const float bx = fmaf(__uint_as_float(w[0]), ix, nx), by = fmaf(__uint_as_float(w[1]), iy, ny), bz = fmaf(__uint_as_float(w[2]), iz, nz);
+#define IRIS_SLABS80(D, C)                                                                                                        \
+    {                                                                                                                             \
+        const iris_h2 hx = __builtin_bit_cast(iris_h2, (uint32_t)w[8 + (C)]), hy = __builtin_bit_cast(iris_h2, (uint32_t)w[12 + (C)]), hz = __builtin_bit_cast(iris_h2, (uint32_t)wz[C]);   \
+        float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
+        float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
+        D = tf - tn;                                                                                                              \
+    }
+    float d0, d1, d2, d3;
+    IRIS_SLABS80(d0, 0) IRIS_SLABS80(d1, 1) IRIS_SLABS80(d2, 2) IRIS_SLABS80(d3, 3)
+#undef IRIS_SLABS80
+#else
+    iris_u16v w;
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(base), "s"(off_s) : "memory");
     uint32_t r0 = w[12], r1 = w[13], r2 = w[14], r3 = w[15];
     const float ax = __uint_as_float(w[3]) * ix, ay = __uint_as_float(w[4]) * iy, az = __uint_as_float(w[5]) * iz;
     const float bx = fmaf(__uint_as_float(w[0]), ix, nx), by = fmaf(__uint_as_float(w[1]), iy, ny), bz = fmaf(__uint_as_float(w[2]), iz, nz);
-    typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
 #if IRIS_SHARED_PAIRS
     // Bytes 0 / 2 and 1 / 3 of a plane word are isolated TOGETHER: w & 0x00ff00ff holds the planes of children 0 and 2 as the two f16 halves of one
     // scalar register, (w >> 8) & 0x00ff00ff those of children 1 and 3 -- on register PAIRS (the six plane words are adjacent), 9 scalar instructions
@@ -411,6 +463,7 @@ __device__ __forceinline__ void node_step_shared(const SceneDev& sc, RayState& r
     IRIS_SLABS(d0, 0) IRIS_SLABS(d1, 1) IRIS_SLABS(d2, 2) IRIS_SLABS(d3, 3)
 #undef IRIS_SLABS
 #undef IRIS_PAIR
+#endif
 #endif
     const int32_t b0 = __float_as_int(d0), b1 = __float_as_int(d1), b2 = __float_as_int(d2), b3 = __float_as_int(d3);
     const int32_t n01 = b0 & b1, n012 = n01 & b2;
@@ -573,7 +626,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
 #endif
 #if IRIS_SCALAR_TOP
             if (!COUNT && LAYOUT == kLayoutQ8 && shared_tries > 0) {
-                const uint32_t off = (r.cur << 6) + r.oct_base;                 // (meaningless in the lanes that are not at a node: masked out below)
+                const uint32_t off = node_offset(r.cur) + r.oct_base;           // (meaningless in the lanes that are not at a node: masked out below)
                 const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __builtin_ctzll(m_node));   // (m_node != 0 here: ctz, not ffs - 1 with its zero case)
                 if (popc_mask(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
                     if (at_node && off == off0) node_step_shared(sc, r, st, off0, IRIS_FAST_PUSH && LDS_DEPTH >= 3 && __ballot(st.sp > LDS_DEPTH - 3) == 0);

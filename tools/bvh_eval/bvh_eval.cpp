@@ -48,12 +48,19 @@ int main(int argc, char** argv) {
     const size_t nn = bvh.nodes.size();
     // Q8 decode: per node, origin = min of child lows, per axis the smallest power of two 2^e with 255 * 2^e >= extent
     std::vector<QNode> q(nn);
+    const bool iso = getenv("BVH_EVAL_ISO") != nullptr;   // ONE plane scale per node (the largest axis extent) instead of one per axis: the 80-B node study of round 5
     for (size_t i = 0; i < nn; ++i) {
         const WideNode& w = bvh.nodes[i];
+        double ext_max = 0;
         for (int k = 0; k < 3; ++k) {
             float org = INFINITY, hi3 = -INFINITY;
             for (int s = 0; s < w.n; ++s) { org = std::min(org, w.lo[s][k]); hi3 = std::max(hi3, w.hi[s][k]); }
-            const double ext = (double)hi3 - (double)org;
+            ext_max = std::max(ext_max, (double)hi3 - (double)org);
+        }
+        for (int k = 0; k < 3; ++k) {
+            float org = INFINITY, hi3 = -INFINITY;
+            for (int s = 0; s < w.n; ++s) { org = std::min(org, w.lo[s][k]); hi3 = std::max(hi3, w.hi[s][k]); }
+            const double ext = iso ? ext_max : (double)hi3 - (double)org;
             int e = -126;
             if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
             while (std::ldexp(255.0, e) < ext) ++e;
