@@ -186,7 +186,7 @@ def test_skipping_the_unused_material_evaluation_changes_nothing(tmp_path):
             res[skip] = (L.detach().clone(), em.radiance.grad.clone(), len(calls))
         assert res[True][2] == 1 and res[False][2] == 2
         assert torch.equal(res[True][0], res[False][0])
-        assert rel_l2(res[True][1].cpu().numpy(), res[False][1].cpu().numpy()) <= 1e-6           # (the backward pass is a scatter of float atomics: equal up to summation order, skip or no skip)
+        assert rel_l2(res[True][1].cpu().numpy(), res[False][1].cpu().numpy()) <= 2e-5           # (the backward pass scatters ~10^5 float atomics into the box room's TWO emitter rows: equal up to summation order, skip or no skip; two runs of ONE mode differ as much)
         assert float(res[True][0].abs().sum()) > 0 and float(res[True][1].abs().sum()) > 0
         # recorded draws (the reference's compacted mode): the same
         u = [T(p[f"u{k}"]) for k in range(5)]
