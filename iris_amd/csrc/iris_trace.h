@@ -16,6 +16,9 @@ constexpr int kStackSpill = 72;      // rarely-touched overflow in scratch (corr
 #ifndef IRIS_NODE80
 #define IRIS_NODE80 0
 #endif
+#ifndef IRIS_SLAB_CVT
+#define IRIS_SLAB_CVT 0
+#endif
 constexpr uint32_t kNodeBytes = IRIS_NODE80 ? 80u : 64u;
 __device__ __forceinline__ uint32_t node_offset(uint32_t cur) { return IRIS_NODE80 ? cur * 80u : cur << 6; }
 constexpr uint32_t kLeafBit = 0x80000000u;
@@ -297,6 +300,19 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         // child into the two halves of a register and v_fma_mix_f32 reads an f16 operand directly: 1 + 2 instructions per axis and child
         // instead of 2 conversions + 2 FMAs.  The node stores scale * 2^24, so q*2^-24 * (scale*2^24*idir) + b is the same real number,
         // rounded once by the FMA.
+#if IRIS_SLAB_CVT
+        // (round 5 experiment) the plane bytes converted by v_cvt_f32_ubyteN and fed to PLAIN v_fma_f32: 12 instructions per child instead of 9, but of two classes that
+        // issue TOGETHER (tools/microbench pair: an integer-pipe instruction followed by a float-pipe one costs ~5 cycles the pair; v_fma_mix_f32 pairs with nothing, 4.4
+        // cycles each).  q * (scale * idir) + b is the same real number as (q * 2^-24) * (scale * 2^24 * idir) + b: the same t, bit for bit.
+        const float ax1 = ax * 0x1p-24f, ay1 = ay * 0x1p-24f, az1 = az * 0x1p-24f;
+#define IRIS_SLABQ(D, C)                                                                                                          \
+    {                                                                                                                             \
+        float tn = fmaxf(fmaxf(fmaf(ubyte(nxq, C), ax1, bx), fmaf(ubyte(nyq, C), ay1, by)), fmaxf(fmaf(ubyte(nzq, C), az1, bz), 0.f));      \
+        float tf = fminf(fminf(fmaf(ubyte(fxq, C), ax1, bx), fmaf(ubyte(fyq, C), ay1, by)), fminf(fmaf(ubyte(fzq, C), az1, bz), r.h.t));    \
+        D = tf - tn;                                                                                                              \
+    }
+#define IRIS_PLANES(NQ, FQ, C) 0
+#else
 #define IRIS_PLANES(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
 #define IRIS_SLABQ(D, C)                                                                                                          \
     {                                                                                                                             \
@@ -305,6 +321,7 @@ __device__ __forceinline__ void node_step(const SceneDev& sc, RayState& r, STACK
         float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
         D = tf - tn;                     /* sign clear: the child is hit (tn <= tf).  tn = tf gives +0; a NaN (inf - inf: tn = tf = inf) with a clear sign  */ \
     }                                    /* would only cost a wasted visit                                                                                */
+#endif
 #endif
         float d0, d1, d2, d3;
         IRIS_SLABQ(d0, 0) IRIS_SLABQ(d1, 1) IRIS_SLABQ(d2, 2) IRIS_SLABQ(d3, 3)

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, unsign
     __builtin_amdgcn_s_barrier();
     const unsigned long long t0 = stamp(), r0 = stamp_real();
     for (int i = 0; i < iters; ++i) {
-#define ONE(k)                                                                                                                   \
+#define EMIT(OP, k)                                                                                                              \
     if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));                                     \
     else if (OP == OP_FMA_MIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(a[k]) : "v"(b), "v"(c));      \
     else if (OP == OP_PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(sel));                            \
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, unsign
     else if (OP == OP_CVT_PKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(a[k]) : "v"(b), "v"(c));                        \
     else if (OP == OP_PK_MIN_F16_PK_FMA) { if (k & 1) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a[k]) : "v"(b));                  \
                                            else asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c)); }
+#define ONE(k) EMIT(OP, k)
         R16(ONE) R16(ONE)
 #undef ONE
     }
@@ -125,6 +126,60 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, unsign
         const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         cyc[w] = t1 - t0; real[w] = r1 - r0;
     }
+}
+
+// Which instruction classes ISSUE TOGETHER (round 5): the same loop with two opcodes alternating, A on the even destination registers, B on the odd ones (all 32
+// instructions of a trip independent of each other).  If A and B can share an issue slot the pair costs what the slower one costs alone; if not, the sum.
+template <int OPA, int OPB>
+__global__ __launch_bounds__(256) void pair_kernel(float* out, int iters, unsigned long long* cyc, unsigned long long* real) {
+    float a[16];
+    float2 p[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a[k] = (float)(threadIdx.x + k) * 1e-3f; p[k] = make_float2(a[k], a[k] + 1.f); }
+    float b = 1.0001f + (float)threadIdx.x * 1e-9f, c = 0.5f;
+    float2 pb = make_float2(b, b), pc = make_float2(c, c);
+    uint32_t sel = 0x0c000c04u;
+    unsigned long long smask = __ballot(threadIdx.x & 1), sm[4] = {0, 0, 0, 0};
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[0]), "v"(b) : "vcc");
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = stamp(), r0 = stamp_real();
+    for (int i = 0; i < iters; ++i) {
+#define TWO(k) if ((k) & 1) { EMIT(OPB, k) } else { EMIT(OPA, k) }
+        R16(TWO) R16(TWO)
+#undef TWO
+    }
+    const unsigned long long t1 = stamp(), r1 = stamp_real();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += a[k] + p[k].x + p[k].y;
+    if (s == 123.456f || (sm[0] ^ sm[1] ^ sm[2] ^ sm[3]) == 0x123456789ull) out[0] = s;
+    if ((threadIdx.x & 63) == 0) {
+        const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        cyc[w] = t1 - t0; real[w] = r1 - r0;
+    }
+    (void)pb; (void)pc; (void)sel; (void)smask;
+}
+template <int OPA, int OPB>
+static void run_pair(int cus, int waves_per_simd, float* d_out, unsigned long long* d_cyc, unsigned long long* d_real) {
+    const int iters = 4096, blocks = cus * waves_per_simd, n_waves = blocks * 4;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((pair_kernel<OPA, OPB>), dim3(blocks), dim3(256), 0, 0, d_out, 64, d_cyc, d_real);
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((pair_kernel<OPA, OPB>), dim3(blocks), dim3(256), 0, 0, d_out, iters, d_cyc, d_real);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> cyc(n_waves);
+    CHECK(hipMemcpy(cyc.data(), d_cyc, n_waves * 8, hipMemcpyDeviceToHost));
+    double c = 0;
+    for (int i = 0; i < n_waves; ++i) c += (double)cyc[i];
+    c /= n_waves;
+    const double insts = (double)iters * 32.0;
+    printf("{\"bench\": \"pair\", \"a\": \"%s\", \"b\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_PAIR_per_simd\": %.3f, \"chip_Gwinst_per_s\": %.1f}\n",
+           kOpName[OPA], kOpName[OPB], waves_per_simd, 2.0 * c / (insts * waves_per_simd), insts * n_waves / (ms * 1e-3) / 1e9);
+    fflush(stdout);
 }
 
 template <int OP>
@@ -411,6 +466,15 @@ int main(int argc, char** argv) {
             run_valu<OP_MUL_HI_U32>(cus, w, d_out, d_cyc, d_real);
             run_valu<OP_MAD_U64>(cus, w, d_out, d_cyc, d_real);
         }
+    }
+    if (!strcmp(what, "pair")) {          // which instruction classes issue together (round 5): A alternating with B, all independent, 7 waves per SIMD
+#define PAIRS_WITH(A) run_pair<A, OP_FMA>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_FMA_MIX>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_PERM>(cus, 7, d_out, d_cyc, d_real); \
+                      run_pair<A, OP_MAX3>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_MAX>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_SUB_F32>(cus, 7, d_out, d_cyc, d_real);   \
+                      run_pair<A, OP_AND>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_ADD_U32>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_LSHL_ADD>(cus, 7, d_out, d_cyc, d_real); \
+                      run_pair<A, OP_MOV>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_CND_SGPR>(cus, 7, d_out, d_cyc, d_real); run_pair<A, OP_CMP_E64>(cus, 7, d_out, d_cyc, d_real); \
+                      run_pair<A, OP_MUL>(cus, 7, d_out, d_cyc, d_real);
+        PAIRS_WITH(OP_FMA_MIX) PAIRS_WITH(OP_FMA) PAIRS_WITH(OP_PERM) PAIRS_WITH(OP_MAX3) PAIRS_WITH(OP_AND) PAIRS_WITH(OP_LSHL_ADD) PAIRS_WITH(OP_CND_SGPR)
+#undef PAIRS_WITH
     }
     if (!strcmp(what, "pk16")) {          // packed half arithmetic (round 4: would slab tests in packed f16 issue faster than v_fma_mix_f32?)
         for (int w : {2, 7}) {
