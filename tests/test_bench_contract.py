@@ -87,6 +87,24 @@ def test_two_ranks_on_one_gpu_line(collective):
 
 
 @pytest.mark.timeout(900)
+def test_the_drivers_launch_form():
+    """the exact form the driver uses for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun's environment) -- here with two gloo ranks sharing the GPU: ONE JSON line on stdout, from rank 0"""
+    from conftest import free_port
+    env = dict(os.environ, IRIS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "120", "--width", "160", "--spp", "32", "--tris", "20000", "--slf-res", "64",
+           "--views", "4", "--cpu-seconds", "0", "--no-extras", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["multi_gpu"]["ranks_seen_by_all_reduce"] == 2
+    assert d["multi_gpu"]["gathered_image_matches_what_the_ranks_sent"] is True and d["parity_check"]["bit_exact"] is True
+
+
+@pytest.mark.timeout(900)
 def test_eight_ranks_on_one_gpu_line():
     """BASELINE configs[3]'s rank count: `bench.py --gpus 8` starts eight workers (spawn_workers), they rendezvous, pass the barriers and the timed loop, send 15
     stripes of 8 rows through the gather (seven ranks own two, the eighth one: padded send rows) and rank 0 prints the one line -- eight gloo ranks sharing this
