@@ -6,10 +6,14 @@ BVH / SLF / emitter tables and bakes only its pixels; ONE collective of the stac
 CPU tests) -- a gather to the rank that writes the files, or an all_gather -- followed by one permutation pass rebuilds the image
 (MapGatherer).  Sample streams are
 keyed by the image-space pixel id, so the gathered image is bit-identical for every world size."""
+import os
+
 import torch
 import torch.distributed as dist
 
-STRIPE_ROWS = 8     # 1080 rows: 135 stripes -> 17 | 16 per rank at N = 8 (max/mean 1.007); 16-row stripes give 144 vs 128 rows (1.067)
+# 1080 rows: 135 stripes -> 17 | 16 per rank at N = 8 (max/mean 1.007); 16-row stripes give 144 vs 128 rows (1.067).  IRIS_STRIPE_ROWS: experiments only
+# (tools/emulate_ranks.sh; every rank of a job must see the same value)
+STRIPE_ROWS = int(os.environ.get("IRIS_STRIPE_ROWS", "8"))
 
 
 def stripe_rows(H, world, rank, stripe=STRIPE_ROWS):
