@@ -19,6 +19,9 @@ constexpr int kStackSpill = 72;      // rarely-touched overflow in scratch (corr
 #ifndef IRIS_SLAB_CVT
 #define IRIS_SLAB_CVT 0
 #endif
+#ifndef IRIS_EXP_NODRAIN
+#define IRIS_EXP_NODRAIN 0
+#endif
 constexpr uint32_t kNodeBytes = IRIS_NODE80 ? 80u : 64u;
 __device__ __forceinline__ uint32_t node_offset(uint32_t cur) { return IRIS_NODE80 ? cur * 80u : cur << 6; }
 constexpr uint32_t kLeafBit = 0x80000000u;
@@ -615,6 +618,11 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if (!more) break;
             continue;
         }
+#if IRIS_EXP_NODRAIN
+        // (UPPER-BOUND EXPERIMENT, wrong results: what would a tile cost without its drain?  When the list is exhausted the rays still in flight are dropped -- retired as misses --
+        //  instead of being traversed to the end at falling lane utilisation.  Never defined in a shipped build.)
+        if (!more) { r.h.slot = -1; r.h.u = r.h.v = 0.f; break; }
+#endif
         // ---------------- node phase
         for (;;) {
             const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
