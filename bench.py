@@ -385,11 +385,13 @@ def main():
                 # how much of the node work a wave does TOGETHER (the scalar-top-of-tree question, EXPERIMENTS.md round 4): node steps in which >= 32 lanes sit at one
                 # node of one octant table, as a share of all node steps / the visits made in them, as a share of all visits / their SIMD lane utilisation
                 "shared_node_steps": {"share_of_node_steps": round(st[15] / max(st[3], 1), 4), "share_of_node_visits": round(st[16] / max(st[1], 1), 4),
-                                      "lanes_at_the_shared_node": round(st[16] / max(st[15], 1), 1), "steps_with_every_lane_at_it": round(st[17] / max(st[3], 1), 4)},
+                                      "lanes_at_the_shared_node": round(st[16] / max(st[15], 1), 1), "steps_with_every_lane_at_it": round(st[17] / max(st[3], 1), 4),
+                                      "share_of_node_steps_executed_through_the_scalar_path": round(st[19] / max(st[3], 1), 4)},
                 "note": "per-RAY counts (node visits, triangle tests, stack depths) do not depend on the schedule; the WAVE-level figures (lane utilisation, iterations, drain) come from instrumented "
-                        "(COUNT) builds, which run the tile code at 4 waves per SIMD and WITHOUT the shared scalar node visits of the timed kernel (iris_trace.h: `!COUNT &&`): they describe the "
-                        "per-lane schedule the shared visits were designed on, not the timed schedule; the timed kernel's own lane utilisation is roofs.valu.simd_lane_utilisation (PMC)"}
-        assert 0 <= st[7] <= st[6] <= st[5] <= st[0] and st[3] * 64 >= st[1], "instrumented counters violate their invariants"
+                        "(COUNT) builds, which since round 5 follow the timed kernel's wave-level schedule (the shared scalar node visits are taken and counted: lanes at other nodes sit such a step "
+                        "out, which the lane utilisation of the node steps includes) at 4 instead of 7 waves per SIMD; the timed kernel's lane utilisation over ALL its instructions is "
+                        "roofs.valu.simd_lane_utilisation (PMC)"}
+        assert 0 <= st[7] <= st[6] <= st[5] <= st[0] and st[3] * 64 >= st[1] and st[19] <= st[3], "instrumented counters violate their invariants"
         # (b) counters of the same kernel from the committed rocprofv3 passes, refused when stale
         pj, src = load_pmc(rays_per_launch, info["node_bytes"])
         roofs, traffic, bound = None, None, None

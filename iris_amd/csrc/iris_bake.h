@@ -21,7 +21,7 @@ struct BakeArgs {
     float* out0; float* out1; int64_t* tri_next;
     int64_t* src_next;          // diagnostics (iris_hip_debug.h): per sample, the radiance-table row that was read (eval_emitter1's src)
     unsigned long long* stats;  // instrumented launches only: 20 slots {rays, node visits, tri tests, wave node iters, wave leaf iters, rays with
-                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, [11..14] node visits with index < 21 / 85 / 341 / 1365, [15..17] wave node iterations with >= 32 lanes at one node / those lanes / iterations with ALL lanes at one node}
+                                // stack > 8 / 12 / 16, (v1) tail sum, node visits / wave node iters while draining, [11..14] node visits with index < 21 / 85 / 341 / 1365, [15..17] wave node iterations with >= 32 lanes at one node / those lanes / iterations with ALL lanes at one node, [18] iterations with checked pushes, [19] iterations executed through the scalar path}
     // tile kernels only
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
@@ -133,8 +133,8 @@ __device__ __forceinline__ void flush_stats(const BakeArgs& a, const TraceStats&
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 11 + k, (unsigned long long)x);
         }
-        uint32_t sh[4] = {ts.shared_iters, ts.shared_lanes, ts.shared_all_iters, ts.slow_push_iters};
-        for (int k = 0; k < 4; ++k) {
+        uint32_t sh[5] = {ts.shared_iters, ts.shared_lanes, ts.shared_all_iters, ts.slow_push_iters, ts.shared_path_iters};
+        for (int k = 0; k < 5; ++k) {
             uint32_t x = sh[k];
             for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
             if ((threadIdx.x & 63) == 0) atomicAdd(a.stats + 15 + k, (unsigned long long)x);

@@ -216,6 +216,7 @@ struct TraceStats {
     uint32_t top21 = 0, top85 = 0, top341 = 0, top1365 = 0;   // node visits with node index < 21 / 85 / 341 / 1365 (nodes are in breadth-first order:
                                                               // the first 1 + 4 + 16 (+ 64 (+ 256 (+ 1024))) nodes are the top 3 (4, 5, 6) levels of a full tree)
     uint32_t slow_push_iters = 0;     // wave node iterations that could not take the branch-free pushes (some lane's stack within three entries of the LDS part's end)
+    uint32_t shared_path_iters = 0;   // wave node iterations EXECUTED through the scalar path (node_step_shared: >= IRIS_SCALAR_TOP lanes at one node, test not gated off)
     uint32_t shared_iters = 0, shared_lanes = 0, shared_all_iters = 0;   // wave node iterations in which >= 32 of the lanes at a node sit at the SAME node of the same
                                                                           // octant table (counted by the first active lane), the lanes that share it, and the
                                                                           // iterations in which every lane at a node does
@@ -650,11 +651,17 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
             if ((!IRIS_IDLE_GATE || n_node <= 64 - kRefillMin) && more && popc_mask(__ballot(r.cur == kEmptyRef)) >= kRefillMin) break;   // enough idle lanes: go refill
 #endif
 #if IRIS_SCALAR_TOP
-            if (!COUNT && LAYOUT == kLayoutQ8 && shared_tries > 0) {
+            if (LAYOUT == kLayoutQ8 && shared_tries > 0) {
                 const uint32_t off = node_offset(r.cur) + r.oct_base;           // (meaningless in the lanes that are not at a node: masked out below)
                 const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, __builtin_ctzll(m_node));   // (m_node != 0 here: ctz, not ffs - 1 with its zero case)
                 if (popc_mask(__ballot(off == off0) & m_node) >= IRIS_SCALAR_TOP) {     // (one compare; the masks are combined and counted on the scalar ALU)
+                    if (COUNT) {      // (instrumented builds follow the SAME wave-level schedule as the timed kernel since round 5: the shared steps are taken and counted)
+                        if (at_node) ts->count_shared(r.cur, r.oct_base);
+                        if (at_node && off == off0) { ts->nodes++; ts->count_top(r.cur); if (!more) ts->drain_nodes++; }
+                        if (first_active_lane()) { ts->node_iters++; ts->shared_path_iters++; if (!more) ts->drain_node_iters++; }
+                    }
                     if (at_node && off == off0) node_step_shared(sc, r, st, off0, IRIS_FAST_PUSH && LDS_DEPTH >= 3 && __ballot(st.sp > LDS_DEPTH - 3) == 0);
+                    if (COUNT) max_sp = max(max_sp, st.sp);
                     shared_tries = kSharedTries;
                     continue;
                 }
