@@ -42,7 +42,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
 
 // ---- diagnostics options (iris_hip_debug.h): process-wide, set by tests / experiments only; -1 = the built-in default
-static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1, g_opt_bvh_presplit_x10 = -1;
+static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1, g_opt_bvh_presplit_x10 = -1, g_opt_joint_max_rays = -1;
 extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     if (!key) return fail(IRIS_ERR_ARG, "iris_debug_set: null key");
     const std::string k(key);
@@ -53,6 +53,7 @@ extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     else if (k == "tile_target_rays") g_opt_tile_target_rays = value;
     else if (k == "tiles_per_block") g_opt_tiles_per_block = value;
     else if (k == "pt_tile_min") g_opt_pt_tile_min = value;
+    else if (k == "joint_max_rays") g_opt_joint_max_rays = value;
     else return fail(IRIS_ERR_ARG, "iris_debug_set: unknown option " + k);
     return IRIS_OK;
 }
@@ -92,6 +93,12 @@ struct iris_emitter {
     bool can_sample = false;
     int64_t n_rad = 0, k = 0;
 };
+
+// Launches of the one-ray-per-lane kernels (iris_intersect, the path-tracing stages below their tiling threshold) of at most this many rays run in LATENCY MODE
+// (iris_trace.h trace_q8_joint: node and triangle loads of an iteration issued together): they do not fill the chip, and what they wait for is their longest wave's
+// dependent round trips.  iris_debug_set("joint_max_rays") overrides (0 = never).  Results do not depend on it.
+constexpr long long kJointMaxRays = 1 << 20;
+static bool joint_launch(int64_t n_rays) { return n_rays <= (g_opt_joint_max_rays >= 0 ? g_opt_joint_max_rays : kJointMaxRays) && !IRIS_NODE80; }
 
 static int grid_for(int64_t n, int block, int max_blocks) {
     int64_t g = (n + block - 1) / block;
@@ -594,14 +601,14 @@ extern "C" IRIS_API int iris_raygen_synthetic(float focal, const float c2w[12], 
 // ======================================================================================================
 // a2 ray_intersect
 // ======================================================================================================
-template <int LAYOUT>
+template <int LAYOUT, bool JOINT = false>
 __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev sc, const float* __restrict__ xs, const float* __restrict__ ds,
                                                            int64_t B, float* __restrict__ pos, float* __restrict__ nrm,
                                                            float* __restrict__ uv, int64_t* __restrict__ idx, uint8_t* __restrict__ valid) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
         f3 o = ld3(xs + i * 3), d = ld3(ds + i * 3);
-        Hit h = trace_bvh4<LAYOUT>(sc, o, d, s_stack + threadIdx.x);
+        Hit h = trace_bvh4<LAYOUT, false, kStackLds, false, JOINT>(sc, o, d, s_stack + threadIdx.x);
         if (h.slot >= 0) {
             f3 p0, p1, p2;
             hit_vertices(sc, h, p0, p1, p2);
@@ -627,7 +634,10 @@ extern "C" IRIS_API int iris_intersect(const iris_scene* s, const float* xs, con
                               int64_t* idx, uint8_t* valid, iris_stream_t stream) {
     if (!s || B < 0 || (B > 0 && (!xs || !ds))) return fail(IRIS_ERR_ARG, "iris_intersect: bad arguments");
     if (B == 0) return IRIS_OK;
-    if (s->dev.layout == kLayoutQ8)
+    if (s->dev.layout == kLayoutQ8 && joint_launch(B))
+        hipLaunchKernelGGL((intersect_kernel<kLayoutQ8, true>), dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
+                           pos, nrm, uv, idx, valid);
+    else if (s->dev.layout == kLayoutQ8)
         hipLaunchKernelGGL(intersect_kernel<kLayoutQ8>, dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
                            pos, nrm, uv, idx, valid);
     else
@@ -1217,7 +1227,8 @@ extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e,
     if (pt_tiling(N, tile_rays, grid)) {
         if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL((pt_tiled_kernel<kLayoutQ8, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
         else hipLaunchKernelGGL((pt_tiled_kernel<kLayoutF32, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
-    } else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    } else if (a.sc.layout == kLayoutQ8 && joint_launch(N)) hipLaunchKernelGGL((pt_nee_kernel<kLayoutQ8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_nee_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
@@ -1240,7 +1251,8 @@ extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* po
     if (pt_tiling(N, tile_rays, grid)) {
         if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL((pt_tiled_kernel<kLayoutQ8, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
         else hipLaunchKernelGGL((pt_tiled_kernel<kLayoutF32, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
-    } else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    } else if (a.sc.layout == kLayoutQ8 && joint_launch(N)) hipLaunchKernelGGL((pt_brdf_trace_kernel<kLayoutQ8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;

@@ -159,15 +159,18 @@ __device__ __forceinline__ void pt_nee_finish(const PtArgs& a, int64_t i, f3 x, 
     a.e1[i] = (emit_valid && ord >= 0) ? ord : -1;
 }
 
-template <int LAYOUT>
-__global__ __launch_bounds__(kBlock) void pt_nee_kernel(PtArgs a) {
+#ifndef IRIS_JOINT_WAVES
+#define IRIS_JOINT_WAVES 5      // min waves per SIMD the latency-mode instantiations are compiled for (unlimited: 104 VGPRs = 4 waves; 5: 96 VGPRs, no spills -- the NEE and the BRDF stage of a call run side by side on two streams: cfg 5 447-457 / 464-466 / 444-459 Mpaths/s at 4 / 5 / 6)
+#endif
+template <int LAYOUT, bool JOINT = false>
+__global__ __launch_bounds__(kBlock, JOINT ? IRIS_JOINT_WAVES : 1) void pt_nee_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
         const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
         f3 wi; float emit_pdf; int64_t emit_tri;
         sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], x, wi, emit_pdf, emit_tri);
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-        Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
+        Hit h = trace_bvh4<LAYOUT, false, kStackLds, false, JOINT>(a.sc, o, wi, s_stack + threadIdx.x);
         pt_nee_finish(a, i, x, n, wo, wi, emit_pdf, emit_tri, h.slot, h.u, h.v);
     }
 }
@@ -208,15 +211,15 @@ __device__ __forceinline__ void pt_next_hit(const PtArgs& a, int64_t i, f3 wi, i
     st3(a.pos_next + i * 3, pn); st3(a.nrm_next + i * 3, nn); a.tri_next[i] = tri; a.valid_next_hit[i] = slot >= 0;
 }
 
-template <int LAYOUT>
-__global__ __launch_bounds__(kBlock) void pt_brdf_trace_kernel(PtArgs a) {
+template <int LAYOUT, bool JOINT = false>
+__global__ __launch_bounds__(kBlock, JOINT ? IRIS_JOINT_WAVES : 1) void pt_brdf_trace_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
         const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
         f3 wi, w; float pdf;
         pt_sample_dir(a, i, wo, n, wi, pdf, w);
         const f3 o = mk3(x.x + kRayEps * wi.x, x.y + kRayEps * wi.y, x.z + kRayEps * wi.z);
-        Hit h = trace_bvh4<LAYOUT>(a.sc, o, wi, s_stack + threadIdx.x);
+        Hit h = trace_bvh4<LAYOUT, false, kStackLds, false, JOINT>(a.sc, o, wi, s_stack + threadIdx.x);
         st3(a.wi_out + i * 3, wi); a.brdf_pdf[i] = pdf; st3(a.brdf_w + i * 3, w);
         pt_next_hit(a, i, wi, h.slot, h.u, h.v);
     }

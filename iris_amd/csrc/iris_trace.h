@@ -128,12 +128,14 @@ __device__ __forceinline__ void ray_xform(f3 o, f3 d, RayXf& x) {
 
 // The test on leaf record `slot`.  Accept iff the edge functions have no two strictly opposite signs, det = U + V + W != 0 and 0 <= t < inf;
 // (b1, b2) = (V, W) / det (p = b0 p0 + b1 p1 + b2 p2), t = (U Az + V Bz + W Cz) * sz / det (z = P[kz] - o[kz]).
-__device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const RayXf& x, Hit& h) {
+__device__ __forceinline__ void tri_load(const SceneDev& sc, int slot, const RayXf& x, iris_f4v& X, iris_f4v& Y, iris_f4v& Z) {
     const uint32_t base = (uint32_t)slot << 6;     // 32-bit byte offset from the (scalar) table base
     const char* tb = reinterpret_cast<const char*>(sc.tris);
-    const iris_f4v X = *(glb_f4v*)(tb + (size_t)(base + x.offx));
-    const iris_f4v Y = *(glb_f4v*)(tb + (size_t)(base + x.offy));
-    const iris_f4v Z = *(glb_f4v*)(tb + (size_t)(base + x.offz));
+    X = *(glb_f4v*)(tb + (size_t)(base + x.offx));
+    Y = *(glb_f4v*)(tb + (size_t)(base + x.offy));
+    Z = *(glb_f4v*)(tb + (size_t)(base + x.offz));
+}
+__device__ __forceinline__ void tri_eval(const iris_f4v X, const iris_f4v Y, const iris_f4v Z, int slot, const RayXf& x, Hit& h) {
     const int id = __float_as_int(Z.w);            // (every plane carries the index)
     const float Atz = Z.x - x.oz, Btz = Z.y - x.oz, Ctz = Z.z - x.oz;
     const float Ax = fmaf(-x.sx, Atz, X.x - x.ox), Ay = fmaf(-x.sy, Atz, Y.x - x.oy);
@@ -163,6 +165,12 @@ __device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const Ray
     // closest hit = lexicographic min of (t, original index)
     if (ok && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.u = u; h.v = v; h.slot = slot; h.id = id; }
 #endif
+}
+
+__device__ __forceinline__ void tri_test(const SceneDev& sc, int slot, const RayXf& x, Hit& h) {
+    iris_f4v X, Y, Z;
+    tri_load(sc, slot, x, X, Y, Z);
+    tri_eval(X, Y, Z, slot, x, h);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -529,9 +537,87 @@ __device__ __forceinline__ void leaf_step(const SceneDev& sc, RayState& r, const
     }
 }
 
+// -------------------------------------------------------------------------------------------------------
+// LATENCY MODE of the one-ray-per-lane driver (round 5; template parameter JOINT of trace_bvh4: the host launches that instantiation of a kernel when the call does not fill the chip).
+// A call of the path-tracing stages traces 262 144 rays (cfg 5): four waves per SIMD for ONE round, so the launch lasts as long as its longest wave, and that
+// wave's length is its number of DEPENDENT memory round trips (tools/bench_pt_stage_scaling.py: 0.17-0.19 ms for any call of up to 131 072 rays).  The phase
+// scheduling of trace_bvh4 serves issue throughput: an iteration is EITHER a node step or a triangle test, and the lanes in the other state wait -- a wave makes
+// as many round trips as the two kinds of steps take one after the other.  Here every iteration first ISSUES the loads of both kinds (the four words of the node
+// for the lanes at a node, the three planes of the triangle for the lanes at a leaf), waits for all of them together and then evaluates both: every lane with work
+// advances in every iteration, one round trip each.  More instructions per ray (both streams are issued whenever any lane needs them), which a launch that leaves
+// the vector ALUs idle does not pay for.  Same arithmetic per ray; the closest hit does not depend on the schedule (lexicographic minimum of (t, index)).
+// -------------------------------------------------------------------------------------------------------
+#if !IRIS_NODE80
+template <class STACK>
+__device__ __forceinline__ void node_eval_q8(RayState& r, STACK& st, const iris_u4v hd, const iris_u4v q1, const iris_u4v q2, const iris_u4v rf) {
+    // (node_step's Q8 arithmetic on words that are already loaded; checked pushes)
+    const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
+    uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
+    const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(q1.x) * iy, az = __uint_as_float(q1.y) * iz;
+    const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
+    const uint32_t nxq = q1.z, nyq = q1.w, nzq = q2.x, fxq = q2.y, fyq = q2.z, fzq = q2.w;
+    typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
+#define IRIS_PL(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
+#define IRIS_SL(D, C)                                                                                                             \
+    {                                                                                                                             \
+        const iris_h2 hx = IRIS_PL(nxq, fxq, C), hy = IRIS_PL(nyq, fyq, C), hz = IRIS_PL(nzq, fzq, C);                             \
+        float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
+        float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
+        D = tf - tn;                                                                                                              \
+    }
+    float d0, d1, d2, d3;
+    IRIS_SL(d0, 0) IRIS_SL(d1, 1) IRIS_SL(d2, 2) IRIS_SL(d3, 3)
+#undef IRIS_SL
+#undef IRIS_PL
+    const int32_t b0 = __float_as_int(d0), b1 = __float_as_int(d1), b2 = __float_as_int(d2), b3 = __float_as_int(d3);
+    const int32_t n01 = b0 & b1, n012 = n01 & b2;
+    if ((n012 & b3) >= 0) {
+        uint32_t c = b2 >= 0 ? r2 : r3;
+        c = b1 >= 0 ? r1 : c;
+        r.cur = b0 >= 0 ? r0 : c;
+        if ((b3 | n012) >= 0) st.push(r3);
+        if ((b2 | n01) >= 0) st.push(r2);
+        if ((b1 | b0) >= 0) st.push(r1);
+    } else {
+        r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+    }
+}
+template <int LDS_DEPTH, bool GLOBAL_OVF>
+__device__ __forceinline__ Hit trace_q8_joint(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, uint32_t* ovf) {
+    RayState r;
+    ray_begin(sc, r, o, d);
+    Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0; st.tid = threadIdx.x;
+    const RayXf xf = leaf_phase_xform(r);
+    iris_u4v hd = {0u, 0u, 0u, 0u}, q1 = hd, q2 = hd, rf = hd;       // (defined once: a lane that does not load in an iteration keeps stale words nobody evaluates)
+    iris_f4v X = {0.f, 0.f, 0.f, 0.f}, Y = X, Z = X;
+    for (;;) {
+        const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
+        const bool at_leaf = r.cur != kEmptyRef && (r.cur & kLeafBit);
+        if (__ballot(at_node || at_leaf) == 0) break;
+        const int slot = (int)((r.cur & 0x7fffffffu) >> 3);
+        if (at_node) {
+            glb_u4v* n = (glb_u4v*)(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(node_offset(r.cur) + r.oct_base));
+            hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3];
+        }
+        if (at_leaf) tri_load(sc, slot, xf, X, Y, Z);
+        asm volatile("" : "+v"(hd), "+v"(q1), "+v"(q2), "+v"(rf), "+v"(X), "+v"(Y), "+v"(Z));      // both groups of loads issued before either is used: ONE round trip
+        if (at_node) node_eval_q8(r, st, hd, q1, q2, rf);
+        if (at_leaf) {
+            tri_eval(X, Y, Z, slot, xf, r.h);
+            r.cur += 7u;
+            if ((r.cur & 7u) == 0u) r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
+        }
+    }
+    return r.h;
+}
+#endif
+
 // One ray per lane, run to completion (primary rays, the path-tracing stages, the pixel-per-wave bake kernel).
-template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false>
+template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false, bool JOINT = false>
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
+#if !IRIS_NODE80
+    if (JOINT && !COUNT && LAYOUT == kLayoutQ8) return trace_q8_joint<LDS_DEPTH, GLOBAL_OVF>(sc, o, d, lds_stack, ovf);      // (its own instantiation: 104 VGPRs against 77-83)
+#endif
     RayState r;
     ray_begin(sc, r, o, d);
     Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0; st.tid = threadIdx.x;

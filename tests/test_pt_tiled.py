@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from test_hip_parity import dev, room_setup, T  # noqa: F401  (fixtures)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -65,3 +67,45 @@ def test_refine_and_pt_single_parity_through_tiles(tmp_path, oracle_mod, force_t
         import inspect
         kw = {k: v for k, v in (("tmp_path", tmp_path), ("oracle_mod", oracle_mod)) if k in inspect.signature(fn).parameters}
         fn(**kw)
+
+
+def test_latency_mode_equals_phase_mode(dev, room_setup):
+    """Small launches of the one-ray-per-lane kernels run in LATENCY MODE (iris_trace.h trace_q8_joint: the node and the triangle loads of an iteration issued together);
+    iris_debug_set('joint_max_rays', 0) forces the phase-scheduled instantiation.  The closest hit does not depend on the schedule: ray_intersect and the two tracing
+    stages give the same bits either way, on incoherent rays (random origins on the surface, random directions)."""
+    from iris_amd import _lib as L
+    from iris_amd.utils.path_tracing import ray_intersect
+    s = room_setup
+    g = torch.Generator().manual_seed(3)
+    n = 40000
+    pick = torch.randint(0, len(s["pos"]), (n,), generator=g)
+    pos = T(s["pos"], dev)[pick.to(dev)].contiguous(); nrm = T(s["nrm"], dev)[pick.to(dev)].contiguous()
+    d = torch.randn(n, 3, generator=g); d = (d / d.norm(dim=1, keepdim=True)).to(dev)
+    o = (pos + 1e-3 * nrm).contiguous()
+    wo = (-d).contiguous()
+    alb = torch.rand(n, 3, generator=g).to(dev); rough = (torch.rand(n, generator=g) * 0.9 + 0.05).to(dev); metal = torch.rand(n, generator=g).to(dev)
+    s1, s2 = torch.rand(n, generator=g).to(dev), torch.rand(n, 2, generator=g).to(dev)
+    lib = L.lib()
+
+    def stages():
+        out = list(ray_intersect(s["sc"], o, d))
+        wi = torch.empty(n, 3, device=dev); pdf = torch.empty(n, device=dev); w = torch.empty(n, 3, device=dev); pn = torch.empty(n, 3, device=dev); nn = torch.empty(n, 3, device=dev)
+        tri = torch.empty(n, device=dev, dtype=torch.int64); hit = torch.empty(n, device=dev, dtype=torch.bool)
+        L.check(lib.iris_pt_brdf_trace(s["sc"].handle, L.ptr(pos), L.ptr(nrm), L.ptr(wo), L.ptr(alb), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), n,
+                                       L.ptr(wi), L.ptr(pdf), L.ptr(w), L.ptr(pn), L.ptr(nn), L.ptr(tri), L.ptr(hit), 0, 0.0, L.stream()))
+        coef1 = torch.empty(n, 3, device=dev); e1 = torch.empty(n, device=dev, dtype=torch.int32)
+        L.check(lib.iris_pt_nee(s["sc"].handle, s["em"].handle(dev), L.ptr(pos), L.ptr(nrm), L.ptr(wo), L.ptr(alb), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), n,
+                                L.ptr(coef1), L.ptr(e1), 1e-6, 1e-6, 1e-6, L.stream()))
+        torch.cuda.synchronize()
+        return out + [wi, pdf, w, pn, nn, tri, hit, coef1, e1]
+    try:
+        L.debug_set("pt_tile_min", 1 << 40)                 # (the one-ray-per-lane kernels, not the tile kernel)
+        L.debug_set("joint_max_rays", 1 << 30)
+        a = stages()
+        L.debug_set("joint_max_rays", 0)
+        b = stages()
+    finally:
+        L.debug_set("joint_max_rays", -1); L.debug_set("pt_tile_min", -1)
+    assert int(a[4].sum()) > 0.9 * n                        # a closed room
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -150,13 +150,16 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the training step in a HIP graph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--material", choices=["ngp", "stub"], default="ngp")
     ap.add_argument("--no-skip", action="store_true", help="evaluate the material network at the sampled hits as the reference does (path_tracing_single skip_unused_material=False)")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="iris_debug_set option (experiments), e.g. joint_max_rays=0")
     ap.add_argument("--pt-tile-min", type=int, default=-1, help="iris_debug_set pt_tile_min: calls of at least this many rays go through the tiled tracing stages (default: the library's)")
     args = ap.parse_args()
     import bench
     dev = torch.device("cuda:0")
+    from iris_amd import _lib as L
     if args.pt_tile_min >= 0:
-        from iris_amd import _lib as L
         L.debug_set("pt_tile_min", args.pt_tile_min)
+    for kv in args.debug_set:
+        L.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
     ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
     room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
     print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph, material=args.material, skip_unused_material=not args.no_skip)))
