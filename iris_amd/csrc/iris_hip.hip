@@ -1276,7 +1276,11 @@ extern "C" IRIS_API int iris_pt_accumulate_fwd(const float* radiance, const int3
                                       iris_stream_t stream) {
     if (B < 0 || spp < 1 || (B > 0 && (!radiance || !e0 || !path_of || !L))) return fail(IRIS_ERR_ARG, "iris_pt_accumulate_fwd: bad arguments");
     if (B == 0) return IRIS_OK;
-    LAUNCH1D(pt_accumulate_fwd_kernel, B, stream, radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp, L);
+    int lpp = 1;
+    while (lpp < spp && lpp < 64) lpp <<= 1;                     // lanes per pixel: min(64, next power of two >= spp)
+    const int64_t n_groups = (B + 64 / lpp - 1) / (64 / lpp);    // one wave per group of 64 / lpp pixels
+    hipLaunchKernelGGL(pt_accumulate_fwd_kernel, dim3(grid_for(n_groups * 64, 256, 8192)), dim3(256), 0, (hipStream_t)stream, radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp, lpp, L);
+    HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
 extern "C" IRIS_API int iris_pt_accumulate_bwd(const float* gL, const int32_t* e0, const int32_t* path_of, const int32_t* e1, const float* coef1,

@@ -328,27 +328,41 @@ __global__ void pt_brdf_finish_kernel(PtArgs a) {
 
 // L[b] = mean_s( radiance[e0] + [active] (coef1*radiance[e1] + (coef2*radiance[e2] + const2)) )   (utils/path_tracing.py:344,382,404,406)
 // path_of: (B*spp) int32 index into the compacted arrays or -1.
-__global__ void pt_accumulate_fwd_kernel(const float* __restrict__ radiance, const int32_t* __restrict__ e0, const int32_t* __restrict__ path_of,
+// One LANE per (pixel, sample): the terms of a pixel are gathered in parallel -- five dependent loads each -- and then added in the order s = 0, 1, ... by every lane of the
+// pixel's group through lane reads, i.e. the SAME sequential float sum as a one-thread-per-pixel loop (the bits of round 1-4's kernel and of the oracle), without its spp
+// dependent round trips per thread (8192 threads x 32 trips: 56 us of a 0.56 ms cfg-5 call; now ~8 us).  lpp = lanes per pixel = min(64, next power of two >= spp).
+__global__ __launch_bounds__(256) void pt_accumulate_fwd_kernel(const float* __restrict__ radiance, const int32_t* __restrict__ e0, const int32_t* __restrict__ path_of,
                                          const int32_t* __restrict__ e1, const float* __restrict__ coef1, const int32_t* __restrict__ e2,
-                                         const float* __restrict__ coef2, const float* __restrict__ const2, int64_t B, int spp,
+                                         const float* __restrict__ coef2, const float* __restrict__ const2, int64_t B, int spp, int lpp,
                                          float* __restrict__ L) {
-    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, sub = lane / lpp, sl = lane - sub * lpp, ppw = 64 / lpp;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_groups = (B + ppw - 1) / ppw;
+    const float inv = 1.0f / (float)spp;
+    for (int64_t g = wave; g < n_groups; g += n_waves) {
+        const int64_t b = g * ppw + sub;
         float ax = 0.f, ay = 0.f, az = 0.f;
-        for (int s = 0; s < spp; ++s) {
-            const int64_t i = b * spp + s;
+        for (int s0 = 0; s0 < spp; s0 += lpp) {                      // (spp > 64: rounds of 64 samples, still in order)
+            const int sidx = s0 + sl;
             f3 l = mk3(0.f, 0.f, 0.f);
-            if (e0[i] >= 0) l = ld3(radiance + (int64_t)e0[i] * 3);
-            const int j = path_of[i];
-            if (j >= 0) {
-                if (e1[j] >= 0) { f3 r = ld3(radiance + (int64_t)e1[j] * 3), c = ld3(coef1 + (int64_t)j * 3); l.x += c.x * r.x; l.y += c.y * r.y; l.z += c.z * r.z; }
-                f3 t2 = ld3(const2 + (int64_t)j * 3);
-                if (e2[j] >= 0) { f3 r = ld3(radiance + (int64_t)e2[j] * 3), c = ld3(coef2 + (int64_t)j * 3); t2.x += c.x * r.x; t2.y += c.y * r.y; t2.z += c.z * r.z; }
-                l.x += t2.x; l.y += t2.y; l.z += t2.z;
+            if (b < B && sidx < spp) {
+                const int64_t i = b * spp + sidx;
+                if (e0[i] >= 0) l = ld3(radiance + (int64_t)e0[i] * 3);
+                const int j = path_of[i];
+                if (j >= 0) {
+                    if (e1[j] >= 0) { f3 r = ld3(radiance + (int64_t)e1[j] * 3), c = ld3(coef1 + (int64_t)j * 3); l.x += c.x * r.x; l.y += c.y * r.y; l.z += c.z * r.z; }
+                    f3 t2 = ld3(const2 + (int64_t)j * 3);
+                    if (e2[j] >= 0) { f3 r = ld3(radiance + (int64_t)e2[j] * 3), c = ld3(coef2 + (int64_t)j * 3); t2.x += c.x * r.x; t2.y += c.y * r.y; t2.z += c.z * r.z; }
+                    l.x += t2.x; l.y += t2.y; l.z += t2.z;
+                }
             }
-            ax += l.x; ay += l.y; az += l.z;
+            const int n = min(lpp, spp - s0);                        // (wave-uniform)
+            for (int k = 0; k < n; ++k) {                            // the sequential sum, by every lane of the group (lane reads within the group)
+                const int src = sub * lpp + k;
+                ax += __shfl(l.x, src); ay += __shfl(l.y, src); az += __shfl(l.z, src);
+            }
         }
-        const float inv = 1.0f / (float)spp;
-        st3(L + b * 3, mk3(ax * inv, ay * inv, az * inv));
+        if (b < B && sl == 0) st3(L + b * 3, mk3(ax * inv, ay * inv, az * inv));
     }
 }
 // d radiance[e] += gL[b]/spp * coef   (scatter-add; few thousand rows, contention is irrelevant at 2.6e5 paths)
