@@ -193,6 +193,12 @@ IRIS_API int iris_pt_primary_emit(const iris_emitter *, const int64_t *tri, int6
 IRIS_API int iris_pt_nee(const iris_scene *, const iris_emitter *, const float *pos, const float *nrm, const float *wo, const float *albedo,
                 const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *coef1, int32_t *e1,
                 float g_eps, float pdf_eps, float mis_eps, iris_stream_t);
+/* :338-344 as ONE launch (the un-compacted mode of path_tracing_single): jitter, closest hit of rays_o[b] + t * wi, the primary hit's emitter ordinal, which paths
+ * continue.  dudv (2,B,spp) as iris_pt_jitter; wi, wo = -wi, pos, nrm (B*spp,3) as iris_pt_jitter / iris_intersect give them; e0, valid_next as iris_pt_primary_emit;
+ * path_of[i] = i where the path continues (a hit that is not an emitter), -1 otherwise. */
+IRIS_API int iris_pt_primary(const iris_scene *, const iris_emitter *, const float *rays_o, const float *rays_d, const float *dxdu, const float *dydv,
+                    const float *dudv, int64_t B, int spp, float *wi, float *wo, float *pos, float *nrm, int32_t *e0, uint8_t *valid_next, int32_t *path_of,
+                    iris_stream_t);
 /* :384-391  lobe sampling + next intersection.  lobe 0: sample_brdf(s1,s2,wo,normal,mat); lobe 1: sample_diffuse(s2,normal)
  * (path_tracing_det_diff :93-97, weight 1); lobe 2: sample_specular(s2,wo,normal,lobe_roughness) (path_tracing_det_spec :174-178),
  * weight = (g0,g1,0). */

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "iris_pt_nee": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _P],
     "iris_pt_brdf_trace": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _F, _P],
     "iris_pt_brdf_finish": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _F, _F, _P],
+    "iris_pt_primary": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "iris_pt_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "iris_pt_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
     "iris_pt_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],

@@ -1213,6 +1213,59 @@ extern "C" IRIS_API int iris_pt_primary_emit(const iris_emitter* e, const int64_
     LAUNCH1D(pt_primary_emit_kernel, N, stream, e->dev, tri, N, e0, valid_next);
     return IRIS_OK;
 }
+// The head of path_tracing_single's un-compacted mode as ONE launch (round 5): :338-340 jitter -> :343 ray_intersect(rays_o.repeat_interleave(spp), wi) -> :344 the primary hit's
+// emitter ordinal -> which paths continue (path_of) -> wo = -wi.  The same arithmetic as iris_pt_jitter + iris_intersect + iris_pt_primary_emit and the torch glue between them
+// (repeat_interleave, where, neg): six launches of a 0.5 ms call.
+template <int LAYOUT, bool JOINT>
+__global__ __launch_bounds__(kBlock) void pt_primary_kernel(SceneDev sc, EmitDev em, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ dxdu,
+                                                            const float* __restrict__ dydv, const float* __restrict__ dudv, int64_t B, int spp, float* __restrict__ wi_out,
+                                                            float* __restrict__ wo_out, float* __restrict__ pos, float* __restrict__ nrm, int32_t* __restrict__ e0,
+                                                            uint8_t* __restrict__ valid_next, int32_t* __restrict__ path_of) {
+    __shared__ uint32_t s_stack[kStackLds * kBlock];
+    const int64_t n = B * spp;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t b = i / spp;
+        const float du = dudv[i] - 0.5f, dv = dudv[n + i] - 0.5f;
+        const f3 d0 = ld3(rays_d + b * 3), dx = ld3(dxdu + b * 3), dy = ld3(dydv + b * 3);
+        const f3 d = t_normalize(mk3((d0.x + dx.x * du) + dy.x * dv, (d0.y + dx.y * du) + dy.y * dv, (d0.z + dx.z * du) + dy.z * dv));   // pt_jitter_kernel
+        const f3 o = ld3(rays_o + b * 3);
+        st3(wi_out + i * 3, d); st3(wo_out + i * 3, mk3(-d.x, -d.y, -d.z));
+        const Hit h = trace_bvh4<LAYOUT, false, kStackLds, false, JOINT>(sc, o, d, s_stack + threadIdx.x);
+        int ord = -1;
+        if (h.slot >= 0) {                                                         // intersect_kernel's outputs
+            f3 p0, p1, p2;
+            hit_vertices(sc, h, p0, p1, p2);
+            st3(pos + i * 3, hit_position(h, p0, p1, p2));
+            f3 nn = t_normalize(hit_normal(p0, p1, p2));
+            if (t_dot(nn, mk3(-d.x, -d.y, -d.z)) < 0.f) nn = mk3(-nn.x, -nn.y, -nn.z);
+            st3(nrm + i * 3, nn);
+            ord = em.emit_ord[h.id];                                               // pt_primary_emit_kernel
+        } else {
+            st3(pos + i * 3, mk3(0.f, 0.f, 0.f)); st3(nrm + i * 3, mk3(0.f, 0.f, 0.f));
+        }
+        const bool cont = h.slot >= 0 && ord < 0;
+        e0[i] = ord; valid_next[i] = cont ? 1 : 0; path_of[i] = cont ? (int32_t)i : -1;
+    }
+}
+extern "C" IRIS_API int iris_pt_primary(const iris_scene* sc, const iris_emitter* e, const float* rays_o, const float* rays_d, const float* dxdu, const float* dydv,
+                               const float* dudv, int64_t B, int spp, float* wi, float* wo, float* pos, float* nrm, int32_t* e0, uint8_t* valid_next, int32_t* path_of,
+                               iris_stream_t stream) {
+    if (!sc || !e || B < 0 || spp < 1 || (B > 0 && (!rays_o || !rays_d || !dxdu || !dydv || !dudv || !wi || !wo || !pos || !nrm || !e0 || !valid_next || !path_of)))
+        return fail(IRIS_ERR_ARG, "iris_pt_primary: bad arguments");
+    if (B == 0) return IRIS_OK;
+    if (B * spp >= ((int64_t)1 << 31)) return fail(IRIS_ERR_ARG, "iris_pt_primary: more than 2^31 paths in one call (path_of is int32)");
+    if (e->dev.nf != sc->info.n_triangles) return fail(IRIS_ERR_ARG, "iris_pt_primary: the emitter tables are for a mesh of another size than the scene's");
+    const int64_t N = B * spp;
+    const dim3 grid(grid_for(N, kBlock, num_cus() * 6));
+    if (sc->dev.layout == kLayoutQ8 && joint_launch(N))
+        hipLaunchKernelGGL((pt_primary_kernel<kLayoutQ8, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, sc->dev, e->dev, rays_o, rays_d, dxdu, dydv, dudv, B, spp, wi, wo, pos, nrm, e0, valid_next, path_of);
+    else if (sc->dev.layout == kLayoutQ8)
+        hipLaunchKernelGGL((pt_primary_kernel<kLayoutQ8, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, sc->dev, e->dev, rays_o, rays_d, dxdu, dydv, dudv, B, spp, wi, wo, pos, nrm, e0, valid_next, path_of);
+    else
+        hipLaunchKernelGGL((pt_primary_kernel<kLayoutF32, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, sc->dev, e->dev, rays_o, rays_d, dxdu, dydv, dudv, B, spp, wi, wo, pos, nrm, e0, valid_next, path_of);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
 extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e, const float* pos, const float* nrm, const float* wo, const float* albedo,
                            const float* roughness, const float* metallic, const float* s1, const float* s2, int64_t N, float* coef1, int32_t* e1,
                            float g_eps, float pdf_eps, float mis_eps, iris_stream_t stream) {

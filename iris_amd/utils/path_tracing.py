@@ -234,19 +234,6 @@ def path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv,
     return _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, int(indir_depth), uniforms, full=True)
 
 
-_CONST = {}
-
-
-def _const_indices(n, dev):
-    """arange(n) and full(n, -1) as int32 on `dev`, built once per size (path_of of the un-compacted mode: one kernel per call instead of three)"""
-    key = (n, str(dev))
-    if key not in _CONST:
-        if len(_CONST) > 8:
-            _CONST.clear()
-        _CONST[key] = (torch.arange(n, device=dev, dtype=torch.int32), torch.full((n,), -1, device=dev, dtype=torch.int32))
-    return _CONST[key]
-
-
 def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv, spp, indir_depth, uniforms, full=False, compact=None, skip_unused_material=True):
     rays_o = L.require_gpu(rays_o, torch.float32, "rays_o").reshape(-1, 3)
     rays_d = L.require_gpu(rays_d, torch.float32, "rays_d").reshape(-1, 3)
@@ -280,13 +267,22 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         L.mark()
         dudv = nxt(2, B, spp)
         wi = torch.empty(B * spp, 3, device=dev)
-        L.check(lib.iris_pt_jitter(L.ptr(rays_d), L.ptr(dx_du), L.ptr(dy_dv), L.ptr(dudv), B, spp, L.ptr(wi), L.stream()))
-        position, normal, _, triangle_idx, _ = ray_intersect(scene, rays_o.repeat_interleave(spp, 0), wi)
         e0 = torch.empty(B * spp, device=dev, dtype=torch.int32)
         valid_next = torch.empty(B * spp, device=dev, dtype=torch.bool)
         eh, sh = emitter_net.handle(dev), emitter_net.slf.handle(dev)
-        L.check(lib.iris_pt_primary_emit(eh, L.ptr(triangle_idx), B * spp, L.ptr(e0), L.ptr(valid_next), L.stream()))
         radiance = emitter_net.radiance
+        if not compact:
+            # the head of the un-compacted mode as ONE launch (iris_pt_primary: jitter, closest hit, emitter ordinal, continuation flags, wo = -wi): the arithmetic
+            # of the three calls and the torch glue of the compacted branch below, bit for bit (tests/test_pt_single.py compares the two modes)
+            N = B * spp
+            position = torch.empty(N, 3, device=dev); normal = torch.empty(N, 3, device=dev); wo = torch.empty(N, 3, device=dev)
+            path_of = torch.empty(N, device=dev, dtype=torch.int32)
+            L.check(lib.iris_pt_primary(scene.handle, eh, L.ptr(rays_o), L.ptr(rays_d), L.ptr(dx_du), L.ptr(dy_dv), L.ptr(dudv), B, spp, L.ptr(wi), L.ptr(wo), L.ptr(position),
+                                        L.ptr(normal), L.ptr(e0), L.ptr(valid_next), L.ptr(path_of), L.stream()))
+        else:
+            L.check(lib.iris_pt_jitter(L.ptr(rays_d), L.ptr(dx_du), L.ptr(dy_dv), L.ptr(dudv), B, spp, L.ptr(wi), L.stream()))
+            position, normal, _, triangle_idx, _ = ray_intersect(scene, rays_o.repeat_interleave(spp, 0), wi)
+            L.check(lib.iris_pt_primary_emit(eh, L.ptr(triangle_idx), B * spp, L.ptr(e0), L.ptr(valid_next), L.stream()))
 
         if compact:
             if not bool(valid_next.any()):          # the reference returns the un-reduced (B*spp,3) tensor here (:347-348)
@@ -298,12 +294,8 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
             path_of = torch.full((B * spp,), -1, device=dev, dtype=torch.int32)
             path_of[sel] = torch.arange(N, device=dev, dtype=torch.int32)
             position, normal, wo = position[sel].contiguous(), normal[sel].contiguous(), (-wi[sel]).contiguous()
-        else:
-            # every path stays at its ray's index; the ones that do not continue keep path_of = -1 and are ignored by the accumulation (their stage
-            # outputs are computed on the zeros ray_intersect returns for a miss, or on the emitter hit, and never read)
-            N = B * spp
-            path_of = torch.where(valid_next, *_const_indices(N, dev))
-            wo = -wi
+        # (un-compacted: every path stays at its ray's index; the ones that do not continue keep path_of = -1 and are ignored by the accumulation -- their stage
+        #  outputs are computed on the zeros a miss returns, or on the emitter hit, and never read)
 
         L.mark("jitter + primary hit")
         mat = material_net(position)
