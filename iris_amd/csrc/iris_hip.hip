@@ -42,7 +42,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" IRIS_API const char* iris_last_error(void) { return g_err.c_str(); }
 
 // ---- diagnostics options (iris_hip_debug.h): process-wide, set by tests / experiments only; -1 = the built-in default
-static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1, g_opt_bvh_presplit_x10 = -1, g_opt_joint_max_rays = -1, g_opt_wide_latency_tree = -1, g_opt_joint_wide = -1;
+static long long g_opt_bvh_tri_cost_x100 = -1, g_opt_bvh_max_leaf = -1, g_opt_phase_min = -1, g_opt_tile_target_rays = -1, g_opt_tiles_per_block = -1, g_opt_pt_tile_min = -1, g_opt_bvh_presplit_x10 = -1, g_opt_joint_max_rays = -1;
 extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     if (!key) return fail(IRIS_ERR_ARG, "iris_debug_set: null key");
     const std::string k(key);
@@ -54,8 +54,6 @@ extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     else if (k == "tiles_per_block") g_opt_tiles_per_block = value;
     else if (k == "pt_tile_min") g_opt_pt_tile_min = value;
     else if (k == "joint_max_rays") g_opt_joint_max_rays = value;
-    else if (k == "joint_wide") g_opt_joint_wide = value;                  // 0: latency-mode launches read the 4-wide tree even where the scene has the 8-wide one (A/B)
-    else if (k == "wide_latency_tree") g_opt_wide_latency_tree = value;      // 0: scenes created from now on get no 8-wide tree (the latency mode runs on the 4-wide one)
     else return fail(IRIS_ERR_ARG, "iris_debug_set: unknown option " + k);
     return IRIS_OK;
 }
@@ -73,10 +71,6 @@ struct iris_scene {
     SceneDev dev{};
     void* d_nodes = nullptr;
     void* d_tris = nullptr;
-    // the 8-wide tree of the latency-mode kernels (iris_trace.h node_eval_q8w8): its own node table (128 B x 8 octant copies) and leaf records; dev8.layout == 0: not built
-    SceneDev dev8{};
-    void* d_nodes8 = nullptr;
-    void* d_tris8 = nullptr;
     iris_scene_info info{};
 };
 struct iris_slf {
@@ -105,7 +99,6 @@ struct iris_emitter {
 // dependent round trips.  iris_debug_set("joint_max_rays") overrides (0 = never).  Results do not depend on it.
 constexpr long long kJointMaxRays = 1 << 20;
 static bool joint_launch(int64_t n_rays) { return n_rays <= (g_opt_joint_max_rays >= 0 ? g_opt_joint_max_rays : kJointMaxRays) && !IRIS_NODE80; }
-static bool wide_launch(const iris_scene* s, int64_t n_rays) { return joint_launch(n_rays) && s->dev8.layout == kLayoutQ8W8 && g_opt_joint_wide != 0; }
 
 static int grid_for(int64_t n, int block, int max_blocks) {
     int64_t g = (n + block - 1) / block;
@@ -281,82 +274,6 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
     s->info.n_vertices = nv; s->info.n_triangles = nf; s->info.layout = layout; s->info.n_nodes = (int32_t)nn;
     s->info.node_bytes = layout == IRIS_BVH4_Q8 ? (int)kNodeBytes : 128; s->info.tri_bytes = 64; s->info.depth = bvh.depth;
     s->info.sah_cost = bvh.sah_cost; s->info.n_leaf_records = (int32_t)nt;
-    if (layout == IRIS_BVH4_Q8 && !IRIS_NODE80 && g_opt_wide_latency_tree != 0) {
-        // ---- the 8-wide tree for the latency-mode kernels: same builder, SAH-optimal collapse to 8 children, per-octant child order; its own leaf records ----
-        WideBvh b8 = build_wide_bvh(verts, nv, faces, nf, 8, max_leaf, 2e-5f, tri_cost, presplit);
-        const size_t n8 = b8.nodes.size(), nt8 = b8.tri_order.size();
-        if (n8 * 128 * 8 < ((size_t)1 << 32) && nt8 < (size_t)(1 << 26) - 1 && 7 * b8.depth + 8 <= kStackLds + kStackSpill) {
-            const uint32_t dummy8 = kLeafBit | ((uint32_t)nt8 << 3) | 1u;
-            auto ref8 = [&](const WideNode& w, int sl) -> uint32_t {
-                if (sl >= w.n) return dummy8;
-                if (w.child[sl] >= 0) return (uint32_t)w.child[sl];
-                return kLeafBit | ((uint32_t)w.leaf_start[sl] << 3) | (uint32_t)w.leaf_count[sl];
-            };
-            std::vector<float> nodes8(n8 * 32 * 8, 0.f);
-            for (size_t i = 0; i < n8; ++i) {
-                const WideNode& w = b8.nodes[i];
-                float org[3], hi3[3];
-                for (int k = 0; k < 3; ++k) {
-                    org[k] = INFINITY; hi3[k] = -INFINITY;
-                    for (int c = 0; c < w.n; ++c) { org[k] = std::min(org[k], w.lo[c][k]); hi3[k] = std::max(hi3[k], w.hi[c][k]); }
-                    if (w.n == 0) { org[k] = 0.f; hi3[k] = 0.f; }
-                }
-                uint8_t q[6][8];
-                float sc3[3];
-                for (int k = 0; k < 3; ++k) {
-                    const double ext = (double)hi3[k] - (double)org[k];
-                    int e = -126;
-                    if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
-                    while (std::ldexp(255.0, e) < ext) ++e;
-                    const double sc = std::ldexp(1.0, e);
-                    sc3[k] = std::ldexp(1.0f, e + 24);
-                    for (int c = 0; c < 8; ++c) {
-                        if (c >= w.n) { q[k][c] = 255; q[3 + k][c] = 0; continue; }
-                        int lo = (int)std::floor(((double)w.lo[c][k] - (double)org[k]) / sc), hi = (int)std::ceil(((double)w.hi[c][k] - (double)org[k]) / sc);
-                        lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
-                        while (lo > 0 && (double)org[k] + lo * sc > (double)w.lo[c][k]) --lo;
-                        while (hi < 255 && (double)org[k] + hi * sc < (double)w.hi[c][k]) ++hi;
-                        if ((double)org[k] + hi * sc < (double)w.hi[c][k]) return fail(IRIS_ERR_BUILD, "iris_scene_create: node quantisation failed (8-wide tree)");
-                        q[k][c] = (uint8_t)lo; q[3 + k][c] = (uint8_t)hi;
-                    }
-                }
-                for (int o = 0; o < 8; ++o) {
-                    float* po = nodes8.data() + ((size_t)o * n8 + i) * 32;
-                    po[0] = org[0]; po[1] = org[1]; po[2] = org[2]; po[3] = sc3[0]; po[4] = sc3[1]; po[5] = sc3[2];
-                    uint8_t qo[6][8];
-                    for (int j = 0; j < 8; ++j) {
-                        const int sl = j < w.n ? (int)w.order[o][j] : j;
-                        for (int k = 0; k < 3; ++k) {
-                            const bool neg = (o >> k) & 1;
-                            qo[k][j] = neg ? q[3 + k][sl] : q[k][sl];
-                            qo[3 + k][j] = neg ? q[k][sl] : q[3 + k][sl];
-                        }
-                        const uint32_t ref = ref8(w, sl);
-                        std::memcpy(&po[20 + j], &ref, 4);
-                    }
-                    // words 8..19: near_x lo, near_x hi, near_y lo, near_y hi | near_z lo, hi, far_x lo, hi | far_y lo, hi, far_z lo, hi   (lo = children 0..3, hi = 4..7)
-                    for (int k = 0; k < 6; ++k) { std::memcpy(&po[8 + 2 * k], &qo[k][0], 4); std::memcpy(&po[9 + 2 * k], &qo[k][4], 4); }
-                }
-            }
-            std::vector<float> tris8((nt8 + 1) * 16, 0.f);
-            { const int32_t none = -1; for (int k = 0; k < 3; ++k) std::memcpy(&tris8[nt8 * 16 + 4 * k + 3], &none, 4); }
-            for (size_t i = 0; i < nt8; ++i) {
-                const int32_t f = b8.tri_order[i];
-                float* p = tris8.data() + i * 16;
-                for (int v = 0; v < 3; ++v) { const float* pv = verts + (int64_t)faces[(int64_t)f * 3 + v] * 3; for (int k = 0; k < 3; ++k) p[4 * k + v] = pv[k]; }
-                for (int k = 0; k < 3; ++k) std::memcpy(&p[4 * k + 3], &f, 4);
-            }
-            if (hipMalloc(&s->d_nodes8, nodes8.size() * 4) == hipSuccess && hipMalloc(&s->d_tris8, tris8.size() * 4) == hipSuccess &&
-                hipMemcpy(s->d_nodes8, nodes8.data(), nodes8.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                hipMemcpy(s->d_tris8, tris8.data(), tris8.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
-                s->dev8 = s->dev;
-                s->dev8.nodes = (const float4*)s->d_nodes8; s->dev8.tris = (const float4*)s->d_tris8; s->dev8.n_nodes = (int)n8; s->dev8.n_tris = (int)nt8;
-                s->dev8.layout = kLayoutQ8W8; s->dev8.oct_stride = (uint32_t)(n8 * 128);
-            } else {                                  // (memory: the latency mode then runs on the 4-wide tree)
-                (void)hipGetLastError(); (void)hipFree(s->d_nodes8); (void)hipFree(s->d_tris8); s->d_nodes8 = s->d_tris8 = nullptr;
-            }
-        }
-    }
     s->info.build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
     return IRIS_OK;
@@ -364,7 +281,7 @@ extern "C" IRIS_API int iris_debug_scene_create(const float* verts, int64_t nv, 
 }
 extern "C" IRIS_API void iris_scene_destroy(iris_scene* s) {
     if (!s) return;
-    (void)hipFree(s->d_nodes); (void)hipFree(s->d_tris); (void)hipFree(s->d_nodes8); (void)hipFree(s->d_tris8);
+    (void)hipFree(s->d_nodes); (void)hipFree(s->d_tris);
     delete s;
 }
 extern "C" IRIS_API int iris_scene_get_info(const iris_scene* s, iris_scene_info* out) {
@@ -685,7 +602,7 @@ extern "C" IRIS_API int iris_raygen_synthetic(float focal, const float c2w[12], 
 // a2 ray_intersect
 // ======================================================================================================
 template <int LAYOUT, bool JOINT = false>
-__global__ __launch_bounds__(kBlock, LAYOUT == kLayoutQ8W8 ? 4 : 1) void intersect_kernel(SceneDev sc, const float* __restrict__ xs, const float* __restrict__ ds,
+__global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev sc, const float* __restrict__ xs, const float* __restrict__ ds,
                                                            int64_t B, float* __restrict__ pos, float* __restrict__ nrm,
                                                            float* __restrict__ uv, int64_t* __restrict__ idx, uint8_t* __restrict__ valid) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
@@ -717,10 +634,7 @@ extern "C" IRIS_API int iris_intersect(const iris_scene* s, const float* xs, con
                               int64_t* idx, uint8_t* valid, iris_stream_t stream) {
     if (!s || B < 0 || (B > 0 && (!xs || !ds))) return fail(IRIS_ERR_ARG, "iris_intersect: bad arguments");
     if (B == 0) return IRIS_OK;
-    if (wide_launch(s, B))
-        hipLaunchKernelGGL((intersect_kernel<kLayoutQ8W8, true>), dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev8, xs, ds, B,
-                           pos, nrm, uv, idx, valid);
-    else if (s->dev.layout == kLayoutQ8 && joint_launch(B))
+    if (s->dev.layout == kLayoutQ8 && joint_launch(B))
         hipLaunchKernelGGL((intersect_kernel<kLayoutQ8, true>), dim3(grid_for(B, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, s->dev, xs, ds, B,
                            pos, nrm, uv, idx, valid);
     else if (s->dev.layout == kLayoutQ8)
@@ -1303,7 +1217,7 @@ extern "C" IRIS_API int iris_pt_primary_emit(const iris_emitter* e, const int64_
 // emitter ordinal -> which paths continue (path_of) -> wo = -wi.  The same arithmetic as iris_pt_jitter + iris_intersect + iris_pt_primary_emit and the torch glue between them
 // (repeat_interleave, where, neg): six launches of a 0.5 ms call.
 template <int LAYOUT, bool JOINT>
-__global__ __launch_bounds__(kBlock, LAYOUT == kLayoutQ8W8 ? 4 : 1) void pt_primary_kernel(SceneDev sc, EmitDev em, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ dxdu,
+__global__ __launch_bounds__(kBlock) void pt_primary_kernel(SceneDev sc, EmitDev em, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ dxdu,
                                                             const float* __restrict__ dydv, const float* __restrict__ dudv, int64_t B, int spp, float* __restrict__ wi_out,
                                                             float* __restrict__ wo_out, float* __restrict__ pos, float* __restrict__ nrm, int32_t* __restrict__ e0,
                                                             uint8_t* __restrict__ valid_next, int32_t* __restrict__ path_of) {
@@ -1343,9 +1257,7 @@ extern "C" IRIS_API int iris_pt_primary(const iris_scene* sc, const iris_emitter
     if (e->dev.nf != sc->info.n_triangles) return fail(IRIS_ERR_ARG, "iris_pt_primary: the emitter tables are for a mesh of another size than the scene's");
     const int64_t N = B * spp;
     const dim3 grid(grid_for(N, kBlock, num_cus() * 6));
-    if (wide_launch(sc, N))
-        hipLaunchKernelGGL((pt_primary_kernel<kLayoutQ8W8, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, sc->dev8, e->dev, rays_o, rays_d, dxdu, dydv, dudv, B, spp, wi, wo, pos, nrm, e0, valid_next, path_of);
-    else if (sc->dev.layout == kLayoutQ8 && joint_launch(N))
+    if (sc->dev.layout == kLayoutQ8 && joint_launch(N))
         hipLaunchKernelGGL((pt_primary_kernel<kLayoutQ8, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, sc->dev, e->dev, rays_o, rays_d, dxdu, dydv, dudv, B, spp, wi, wo, pos, nrm, e0, valid_next, path_of);
     else if (sc->dev.layout == kLayoutQ8)
         hipLaunchKernelGGL((pt_primary_kernel<kLayoutQ8, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, sc->dev, e->dev, rays_o, rays_d, dxdu, dydv, dudv, B, spp, wi, wo, pos, nrm, e0, valid_next, path_of);
@@ -1368,8 +1280,7 @@ extern "C" IRIS_API int iris_pt_nee(const iris_scene* sc, const iris_emitter* e,
     if (pt_tiling(N, tile_rays, grid)) {
         if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL((pt_tiled_kernel<kLayoutQ8, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
         else hipLaunchKernelGGL((pt_tiled_kernel<kLayoutF32, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
-    } else if (wide_launch(sc, N)) { a.sc = sc->dev8; hipLaunchKernelGGL((pt_nee_kernel<kLayoutQ8W8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a); }
-    else if (a.sc.layout == kLayoutQ8 && joint_launch(N)) hipLaunchKernelGGL((pt_nee_kernel<kLayoutQ8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    } else if (a.sc.layout == kLayoutQ8 && joint_launch(N)) hipLaunchKernelGGL((pt_nee_kernel<kLayoutQ8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_nee_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_nee_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -1393,8 +1304,7 @@ extern "C" IRIS_API int iris_pt_brdf_trace(const iris_scene* sc, const float* po
     if (pt_tiling(N, tile_rays, grid)) {
         if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL((pt_tiled_kernel<kLayoutQ8, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
         else hipLaunchKernelGGL((pt_tiled_kernel<kLayoutF32, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, tile_rays);
-    } else if (wide_launch(sc, N)) { a.sc = sc->dev8; hipLaunchKernelGGL((pt_brdf_trace_kernel<kLayoutQ8W8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a); }
-    else if (a.sc.layout == kLayoutQ8 && joint_launch(N)) hipLaunchKernelGGL((pt_brdf_trace_kernel<kLayoutQ8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    } else if (a.sc.layout == kLayoutQ8 && joint_launch(N)) hipLaunchKernelGGL((pt_brdf_trace_kernel<kLayoutQ8, true>), dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else if (a.sc.layout == kLayoutQ8) hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutQ8>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pt_brdf_trace_kernel<kLayoutF32>, dim3(grid_for(N, kBlock, num_cus() * 6)), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

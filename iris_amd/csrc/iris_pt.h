@@ -163,7 +163,7 @@ __device__ __forceinline__ void pt_nee_finish(const PtArgs& a, int64_t i, f3 x, 
 #define IRIS_JOINT_WAVES 5      // min waves per SIMD the latency-mode instantiations are compiled for (unlimited: 104 VGPRs = 4 waves; 5: 96 VGPRs, no spills -- the NEE and the BRDF stage of a call run side by side on two streams: cfg 5 447-457 / 464-466 / 444-459 Mpaths/s at 4 / 5 / 6)
 #endif
 template <int LAYOUT, bool JOINT = false>
-__global__ __launch_bounds__(kBlock, JOINT ? (LAYOUT == kLayoutQ8W8 ? 4 : IRIS_JOINT_WAVES) : 1) void pt_nee_kernel(PtArgs a) {      // (8-wide: 128 VGPRs, the four waves per SIMD of a 262 144-ray call resident at once)
+__global__ __launch_bounds__(kBlock, JOINT ? IRIS_JOINT_WAVES : 1) void pt_nee_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
         const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);
@@ -212,7 +212,7 @@ __device__ __forceinline__ void pt_next_hit(const PtArgs& a, int64_t i, f3 wi, i
 }
 
 template <int LAYOUT, bool JOINT = false>
-__global__ __launch_bounds__(kBlock, JOINT ? (LAYOUT == kLayoutQ8W8 ? 4 : IRIS_JOINT_WAVES) : 1) void pt_brdf_trace_kernel(PtArgs a) {
+__global__ __launch_bounds__(kBlock, JOINT ? IRIS_JOINT_WAVES : 1) void pt_brdf_trace_kernel(PtArgs a) {
     __shared__ uint32_t s_stack[kStackLds * kBlock];
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.N; i += (int64_t)gridDim.x * kBlock) {
         const f3 x = ld3(a.pos + i * 3), n = ld3(a.nrm + i * 3), wo = ld3(a.wo + i * 3);

@@ -246,7 +246,7 @@ constexpr int kPhaseMin = 12;      // (round 3 sweep at 4096-ray tiles: 10: 7.47
 // {origin.xyz, scale.x | scale.y, scale.z, qlo_x, qlo_y | qlo_z, qhi_x, qhi_y, qhi_z | ref[4]} with 8-bit planes relative to the node's
 // own box (4 dwordx4 per visit): plane = origin + q * 2^e per axis (the node stores 2^(e+24) as a float, see node_step), lo rounded down /
 // hi rounded up, so the decoded box contains the f32 box.
-constexpr int kLayoutF32 = 1, kLayoutQ8 = 3, kLayoutQ8W8 = 5;      // (Q8W8: the 8-wide table of the latency-mode kernels, trace_q8_joint)
+constexpr int kLayoutF32 = 1, kLayoutQ8 = 3;
 __device__ __forceinline__ float ubyte(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xffu); }
 
 // Per-lane traversal state shared by the two drivers below (kept in registers; the struct is scalar-replaced).
@@ -582,58 +582,13 @@ __device__ __forceinline__ void node_eval_q8(RayState& r, STACK& st, const iris_
         r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
     }
 }
-// The 8-wide node of the latency mode (round 5).  A launch that is bound by its longest wave's dependent round trips wants FEWER, FATTER steps: the SAH-optimal collapse to 8 children
-// visits 16.6 nodes per ray where the 4-wide tree visits 24.2 (tools/bvh_eval on the bake kernel's rays), for 37 % more slab tests -- the trade that loses where issue binds
-// (EXPERIMENTS.md round 5: not built for the bake) and wins where latency does.  128-B record per ray octant, children in the octant's front-to-back order:
-//   {origin.xyz, scale.x} {scale.y, scale.z, -, -} {near_x[0..3], near_x[4..7], near_y[0..3], near_y[4..7]} {near_z lo, hi, far_x lo, hi} {far_y lo, hi, far_z lo, hi} {ref[0..3]} {ref[4..7]}
-// The scene keeps this table (and its own leaf-record table: the collapse decides the leaves) beside the 4-wide one; only the latency-mode kernels read it.
-template <class STACK>
-__device__ __forceinline__ void node_eval_q8w8(RayState& r, STACK& st, const iris_u4v hd, const iris_u4v h2, const iris_u4v q1, const iris_u4v q2, const iris_u4v q3, const iris_u4v ra, const iris_u4v rb) {
-    const float ix = r.ix, iy = r.iy, iz = r.iz, nx = r.nx, ny = r.ny, nz = r.nz;
-    uint32_t rf[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    const float ax = __uint_as_float(hd.w) * ix, ay = __uint_as_float(h2.x) * iy, az = __uint_as_float(h2.y) * iz;
-    const float bx = fmaf(__uint_as_float(hd.x), ix, nx), by = fmaf(__uint_as_float(hd.y), iy, ny), bz = fmaf(__uint_as_float(hd.z), iz, nz);
-    typedef _Float16 iris_h2 __attribute__((ext_vector_type(2)));
-#define IRIS_P8(NQ, FQ, C) __builtin_bit_cast(iris_h2, __builtin_amdgcn_perm(NQ, FQ, 0x0c000c04u | ((uint32_t)(C) << 16) | (uint32_t)(C)))
-#define IRIS_S8(D, NX, FX, NY, FY, NZ, FZ, C)                                                                                     \
-    {                                                                                                                             \
-        const iris_h2 hx = IRIS_P8(NX, FX, C), hy = IRIS_P8(NY, FY, C), hz = IRIS_P8(NZ, FZ, C);                                   \
-        float tn = fmaxf(fmaxf(fmaf((float)hx.x, ax, bx), fmaf((float)hy.x, ay, by)), fmaxf(fmaf((float)hz.x, az, bz), 0.f));      \
-        float tf = fminf(fminf(fmaf((float)hx.y, ax, bx), fmaf((float)hy.y, ay, by)), fminf(fmaf((float)hz.y, az, bz), r.h.t));    \
-        D = tf - tn;                                                                                                              \
-    }
-    float d[8];
-    IRIS_S8(d[0], q1.x, q2.z, q1.z, q3.x, q2.x, q3.z, 0) IRIS_S8(d[1], q1.x, q2.z, q1.z, q3.x, q2.x, q3.z, 1)
-    IRIS_S8(d[2], q1.x, q2.z, q1.z, q3.x, q2.x, q3.z, 2) IRIS_S8(d[3], q1.x, q2.z, q1.z, q3.x, q2.x, q3.z, 3)
-    IRIS_S8(d[4], q1.y, q2.w, q1.w, q3.y, q2.y, q3.w, 0) IRIS_S8(d[5], q1.y, q2.w, q1.w, q3.y, q2.y, q3.w, 1)
-    IRIS_S8(d[6], q1.y, q2.w, q1.w, q3.y, q2.y, q3.w, 2) IRIS_S8(d[7], q1.y, q2.w, q1.w, q3.y, q2.y, q3.w, 3)
-#undef IRIS_S8
-#undef IRIS_P8
-    int32_t b[8], none[8];                      // sign set: child j not hit; none[j]: sign set iff none of the children 0 .. j-1 is hit
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = __float_as_int(d[j]);
-    none[0] = (int32_t)0x80000000;
-#pragma unroll
-    for (int j = 1; j < 8; ++j) none[j] = none[j - 1] & b[j - 1];
-    if ((none[7] & b[7]) >= 0) {                // some child is hit: the first one in visiting order is next, the others wait on the stack, the farthest at the bottom
-        uint32_t c = rf[7];
-#pragma unroll
-        for (int j = 6; j >= 0; --j) c = b[j] >= 0 ? rf[j] : c;
-        r.cur = c;
-#pragma unroll
-        for (int j = 7; j >= 1; --j)
-            if ((b[j] | none[j]) >= 0) st.push(rf[j]);
-    } else {
-        r.cur = st.sp > 0 ? st.pop() : kEmptyRef;
-    }
-}
-template <int LDS_DEPTH, bool GLOBAL_OVF, bool WIDE>
+template <int LDS_DEPTH, bool GLOBAL_OVF>
 __device__ __forceinline__ Hit trace_q8_joint(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, uint32_t* ovf) {
     RayState r;
     ray_begin(sc, r, o, d);
     Stack<LDS_DEPTH, GLOBAL_OVF> st; st.lds = (lds_u32*)lds_stack; st.ovf = ovf; st.sp = 0; st.tid = threadIdx.x;
     const RayXf xf = leaf_phase_xform(r);
-    iris_u4v hd = {0u, 0u, 0u, 0u}, q1 = hd, q2 = hd, rf = hd, h2 = hd, q3 = hd, rb = hd;       // (defined once: a lane that does not load in an iteration keeps stale words nobody evaluates)
+    iris_u4v hd = {0u, 0u, 0u, 0u}, q1 = hd, q2 = hd, rf = hd;       // (defined once: a lane that does not load in an iteration keeps stale words nobody evaluates)
     iris_f4v X = {0.f, 0.f, 0.f, 0.f}, Y = X, Z = X;
     for (;;) {
         const bool at_node = r.cur != kEmptyRef && !(r.cur & kLeafBit);
@@ -641,18 +596,12 @@ __device__ __forceinline__ Hit trace_q8_joint(const SceneDev& sc, f3 o, f3 d, ui
         if (__ballot(at_node || at_leaf) == 0) break;
         const int slot = (int)((r.cur & 0x7fffffffu) >> 3);
         if (at_node) {
-            glb_u4v* n = (glb_u4v*)(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)((WIDE ? r.cur << 7 : node_offset(r.cur)) + r.oct_base));
-            if (WIDE) { hd = n[0]; h2 = n[1]; q1 = n[2]; q2 = n[3]; q3 = n[4]; rf = n[5]; rb = n[6]; }
-            else { hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3]; }
+            glb_u4v* n = (glb_u4v*)(reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)(node_offset(r.cur) + r.oct_base));
+            hd = n[0]; q1 = n[1]; q2 = n[2]; rf = n[3];
         }
         if (at_leaf) tri_load(sc, slot, xf, X, Y, Z);
-        // both groups of loads issued before either is used: ONE round trip
-        if (WIDE) asm volatile("" : "+v"(hd), "+v"(h2), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(rf), "+v"(rb), "+v"(X), "+v"(Y), "+v"(Z));
-        else asm volatile("" : "+v"(hd), "+v"(q1), "+v"(q2), "+v"(rf), "+v"(X), "+v"(Y), "+v"(Z));
-        if (at_node) {
-            if (WIDE) node_eval_q8w8(r, st, hd, h2, q1, q2, q3, rf, rb);
-            else node_eval_q8(r, st, hd, q1, q2, rf);
-        }
+        asm volatile("" : "+v"(hd), "+v"(q1), "+v"(q2), "+v"(rf), "+v"(X), "+v"(Y), "+v"(Z));      // both groups of loads issued before either is used: ONE round trip
+        if (at_node) node_eval_q8(r, st, hd, q1, q2, rf);
         if (at_leaf) {
             tri_eval(X, Y, Z, slot, xf, r.h);
             r.cur += 7u;
@@ -666,9 +615,8 @@ __device__ __forceinline__ Hit trace_q8_joint(const SceneDev& sc, f3 o, f3 d, ui
 // One ray per lane, run to completion (primary rays, the path-tracing stages, the pixel-per-wave bake kernel).
 template <int LAYOUT, bool COUNT = false, int LDS_DEPTH = kStackLds, bool GLOBAL_OVF = false, bool JOINT = false>
 __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32_t* lds_stack, TraceStats* ts = nullptr, uint32_t* ovf = nullptr) {
-    static_assert(LAYOUT != kLayoutQ8W8 || (JOINT && !COUNT && !IRIS_NODE80), "the 8-wide table is read by the latency-mode driver only");
 #if !IRIS_NODE80
-    if (JOINT && !COUNT && (LAYOUT == kLayoutQ8 || LAYOUT == kLayoutQ8W8)) return trace_q8_joint<LDS_DEPTH, GLOBAL_OVF, LAYOUT == kLayoutQ8W8>(sc, o, d, lds_stack, ovf);      // (its own instantiations: > 100 VGPRs against 77-83)
+    if (JOINT && !COUNT && LAYOUT == kLayoutQ8) return trace_q8_joint<LDS_DEPTH, GLOBAL_OVF>(sc, o, d, lds_stack, ovf);      // (its own instantiation: 104 VGPRs against 77-83)
 #endif
     RayState r;
     ray_begin(sc, r, o, d);

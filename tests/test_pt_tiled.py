@@ -72,8 +72,7 @@ def test_refine_and_pt_single_parity_through_tiles(tmp_path, oracle_mod, force_t
 def test_latency_mode_equals_phase_mode(dev, room_setup):
     """Small launches of the one-ray-per-lane kernels run in LATENCY MODE (iris_trace.h trace_q8_joint: the node and the triangle loads of an iteration issued together);
     iris_debug_set('joint_max_rays', 0) forces the phase-scheduled instantiation.  The closest hit does not depend on the schedule: ray_intersect and the two tracing
-    stages give the same bits either way -- and on either tree: the latency mode reads the scene's 8-WIDE tree (fewer, fatter dependent steps), whose leaves and leaf
-    records are its own --, on incoherent rays (random origins on the surface, random directions)."""
+    stages give the same bits either way, on incoherent rays (random origins on the surface, random directions)."""
     from iris_amd import _lib as L
     from iris_amd.utils.path_tracing import ray_intersect
     s = room_setup
@@ -102,13 +101,11 @@ def test_latency_mode_equals_phase_mode(dev, room_setup):
     try:
         L.debug_set("pt_tile_min", 1 << 40)                 # (the one-ray-per-lane kernels, not the tile kernel)
         L.debug_set("joint_max_rays", 1 << 30)
-        a = stages()                                        # latency mode on the scene's 8-wide tree (iris_trace.h node_eval_q8w8)
-        L.debug_set("joint_wide", 0)
-        c = stages()                                        # latency mode on the 4-wide tree
+        a = stages()
         L.debug_set("joint_max_rays", 0)
-        b = stages()                                        # the phase-scheduled kernels
+        b = stages()
     finally:
-        L.debug_set("joint_max_rays", -1); L.debug_set("pt_tile_min", -1); L.debug_set("joint_wide", -1)
+        L.debug_set("joint_max_rays", -1); L.debug_set("pt_tile_min", -1)
     assert int(a[4].sum()) > 0.9 * n                        # a closed room
-    for x, y, z in zip(a, b, c):
-        assert torch.equal(x, y) and torch.equal(x, z)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -36,9 +36,8 @@ def main():
         tri = torch.empty(N, device=dev, dtype=torch.int64); hit = torch.empty(N, device=dev, dtype=torch.bool)
         row = {"rays": N, "waves_per_simd_if_all_resident": round(N / 64 / 1024, 2)}
         ref = None
-        for name, tile_min, joint, wide in (("one_ray_per_thread", 1 << 40, 0, 0), ("one_ray_per_thread_latency_mode", 1 << 40, 1 << 40, 0),
-                                            ("one_ray_per_thread_latency_mode_8_wide_tree", 1 << 40, 1 << 40, 1), ("tile_sorted", 0, 0, 0)):
-            L.debug_set("pt_tile_min", tile_min); L.debug_set("joint_max_rays", joint); L.debug_set("joint_wide", wide)
+        for name, tile_min, joint in (("one_ray_per_thread", 1 << 40, 0), ("one_ray_per_thread_latency_mode", 1 << 40, 1 << 40), ("tile_sorted", 0, 0)):
+            L.debug_set("pt_tile_min", tile_min); L.debug_set("joint_max_rays", joint)
 
             def call():
                 L.check(lib.iris_pt_brdf_trace(scene.handle, L.ptr(pos), L.ptr(nrm), L.ptr(wo), L.ptr(alb), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
@@ -55,7 +54,7 @@ def main():
                 ref = tri.clone()
             else:
                 row["same_hits"] = row.get("same_hits", True) and bool(torch.equal(ref, tri))
-        L.debug_set("pt_tile_min", -1); L.debug_set("joint_max_rays", -1); L.debug_set("joint_wide", -1)
+        L.debug_set("pt_tile_min", -1); L.debug_set("joint_max_rays", -1)
         rows.append(row)
     print(json.dumps({"stage": "iris_pt_brdf_trace (sample_brdf + closest hit), bench scene 1.0 M triangles, random pixels of view 0 x spp 32", "rows": rows}))
 
