@@ -562,6 +562,10 @@ def main():
         result["extras"]["cfg5_path_tracing_single_network_evaluated_twice_as_the_reference"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="ngp",
                                                                                                                     skip_unused_material=False, stages=False)
         result["extras"]["cfg5_path_tracing_single_stub_material"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="stub", stages=False)
+        # ---- refine_shading's diffuse pass (spp 128, 5 bounces, NEE + MIS) through the same network: the reference's batch and this build's default (16 x)
+        from tools import bench_refine
+        result["extras"]["refine_diffuse_pass_reference_batch"] = bench_refine.run_f1(scene, emitter, slf_np, dev, batch_pixels=10240, batches=4)
+        result["extras"]["refine_diffuse_pass_default_batch"] = bench_refine.run_f1(scene, emitter, slf_np, dev, batch_pixels=163840, batches=2)
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----

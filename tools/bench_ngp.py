@@ -73,8 +73,11 @@ def main():
         pos_r = pos[perm0].contiguous()
         run(pos_r, "surface_points_random_order")
 
+        bits = int(os.environ.get("NGP_SORT_BITS", "10"))          # bits per axis of the sort key (experiments: how coarse may the ordering be?)
+
         def morton_perm(p):
             q = ((p + 3.0) * (1024.0 / 6.0)).to(torch.int64).clamp_(0, 1023)
+            q = (q >> (10 - bits)) << (10 - bits)
             def spread(v):
                 v = (v | (v << 16)) & 0x030000FF
                 v = (v | (v << 8)) & 0x0300F00F
