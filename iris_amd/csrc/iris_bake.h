@@ -32,6 +32,12 @@ struct BakeArgs {
 #ifndef IRIS_TILE_RAYS
 #define IRIS_TILE_RAYS 5120
 #endif
+#ifndef IRIS_EXP_NOSAMPLE
+#define IRIS_EXP_NOSAMPLE 0
+#endif
+#ifndef IRIS_EXP_NOSHADE
+#define IRIS_EXP_NOSHADE 0
+#endif
 constexpr int kTileRays = IRIS_TILE_RAYS;   // capacity of the LDS ray list (10 KiB) = largest spp of the tile kernels; the host aims at tiles of this size
 
 // lanes-per-pixel / pixels-per-wave geometry of the per-pixel reduction (shared by all bake kernels so that the sums match)
@@ -255,7 +261,13 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
             if (frames) { const float* f = s_frames + pl * 6; t = mk3(f[0], f[1], f[2]); b = mk3(f[3], f[4], f[5]); }
             else normal_space(n, t, b);
             f3 wi; float g0, g1;
+#if IRIS_EXP_NOSAMPLE
+            // (UPPER-BOUND EXPERIMENT, wrong results: what does the sampling arithmetic cost?  A direction from three multiplies instead of Philox + the samplers; never shipped)
+            { const float fs = (float)(s & 15) * 0.0625f - 0.47f, ft = (float)(s >> 4) * 0.125f - 0.45f;
+              wi = t_normalize(mk3(n.x + fs * t.x + ft * b.x, n.y + fs * t.y + ft * b.y, n.z + fs * t.z + ft * b.z)); g0 = 1.f; g1 = 0.5f; (void)base; (void)w; }
+#else
             sample_lobe<SPEC>(a, p, s, n, w, t, b, base, wi, g0, g1);
+#endif
             res[r] = make_float4(wi.x, wi.y, wi.z, 0.f);
             if (SPEC) res_g[r] = make_float2(g1, g0);
             return dir_bin(wi);
@@ -283,6 +295,11 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
             const int s = rr * 64 + sl;
             if (pvalid && s < spp) {
                 const float4 qa = res[pl * spp + s];
+#if IRIS_EXP_NOSHADE
+                // (UPPER-BOUND EXPERIMENT, wrong results: what does the shading pass cost?  The hit record is summed as it is; never shipped)
+                a0x += qa.x; a0y += qa.y; a0z += qa.z; if (SPEC) { a1x += qa.x; a1y += qa.y; a1z += qa.z; }
+                continue;
+#endif
                 Hit h; h.u = qa.x; h.v = qa.y; h.slot = __float_as_int(qa.z); h.t = 0.f; h.id = 0;
                 f3 pn = mk3(0.f, 0.f, 0.f);
                 int64_t tri = -1;
