@@ -558,10 +558,10 @@ def main():
         #  through the closed-form stand-in those rounds used)
         #  through the closed-form stand-in those rounds used; the stages of a call are timed with HIP events and the two leaders priced: the network against the L2
         #  line roof, the BRDF-sampled rays against this run's own bake-kernel ray rate)
-        result.setdefault("extras", {})["cfg5_path_tracing_single"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="ngp", bake_mrays_per_s=result["value"])
-        result["extras"]["cfg5_path_tracing_single_network_evaluated_twice_as_the_reference"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="ngp",
+        result.setdefault("extras", {})["cfg5_path_tracing_single"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", bake_mrays_per_s=result["value"])
+        result["extras"]["cfg5_path_tracing_single_network_evaluated_twice_as_the_reference"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp",
                                                                                                                     skip_unused_material=False, stages=False)
-        result["extras"]["cfg5_path_tracing_single_stub_material"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=10, warmup=2, material="stub", stages=False)
+        result["extras"]["cfg5_path_tracing_single_stub_material"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="stub", stages=False)
         # ---- refine_shading's diffuse pass (spp 128, 5 bounces, NEE + MIS) through the same network: the reference's batch and this build's default (16 x)
         from tools import bench_refine
         result["extras"]["refine_diffuse_pass_reference_batch"] = bench_refine.run_f1(scene, emitter, slf_np, dev, batch_pixels=10240, batches=4)
