@@ -303,15 +303,19 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
                 Hit h; h.u = qa.x; h.v = qa.y; h.slot = __float_as_int(qa.z); h.t = 0.f; h.id = 0;
                 f3 pn = mk3(0.f, 0.f, 0.f);
                 int64_t tri = -1;
+                int ord_rec = -1;
                 if (h.slot >= 0) {
                     const float4* tr = a.sc.tris + (int64_t)h.slot * 4;
                     const float4 tx = tr[0], ty = tr[1], tz = tr[2];      // component-major record (iris_trace.h)
+                    // (fused records, a.em.emit_ord == NULL, wave-uniform: the record's fourth plane carries the triangle's emitter ordinal -- a fourth load from the line the
+                    //  other three come from instead of a gather into the 4 MB ordinal table: one scattered L2 request per sample less)
+                    if (!a.em.emit_ord) ord_rec = __float_as_int(tr[3].x);
                     pn = hit_position(h, mk3(tx.x, ty.x, tz.x), mk3(tx.y, ty.y, tz.y), mk3(tx.z, ty.z, tz.z));
                     tri = __float_as_int(tx.w);
                 }
                 if (a.tri_next) a.tri_next[(p0 + pl) * spp + s] = tri;
                 float epdf; bool vn; int src;
-                const f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn, src);
+                const f3 Le = eval_emitter1(a.em, a.slf, pn, tri, true, 1.0f, 0.0f, epdf, vn, src, ord_rec);
                 if (a.src_next) a.src_next[(p0 + pl) * spp + s] = src;
                 if (SPEC) {
                     const float2 qb = res_g[pl * spp + s];   // (g1, g0)

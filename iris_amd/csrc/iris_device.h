@@ -237,13 +237,15 @@ __device__ __forceinline__ f3 slf_forward(const SlfDev& s, f3 p) { int j; return
 // model/emitter.py:180-221 eval_emitter, one sample.  tri = original triangle index or -1.
 // src (diagnostics): which table row the radiance came from: -2 - emitter ordinal for an emitter triangle, the VoxelSLF row for the
 // radiance cache, -1 for empty space / a miss / no lookup.
+// (ord_known: the emitter ordinal of `tri` when the caller has it already -- the fused bake kernels read it from the hit triangle's record, where the host put it
+//  beside the vertices (iris_hip.hip fused_tris): one scattered 64-B line request per sample less; e.emit_ord is NULL then)
 __device__ __forceinline__ f3 eval_emitter1(const EmitDev& e, const SlfDev& s, f3 p, int64_t tri, bool has_rough,
-                                            float rough, float trace_rough, float& emit_pdf, bool& valid_next, int& src) {
+                                            float rough, float trace_rough, float& emit_pdf, bool& valid_next, int& src, int ord_known = -1) {
     bool vis = tri != -1;
     f3 Le = mk3(0.f, 0.f, 0.f);
     emit_pdf = 0.f;
     int ord = -1;
-    if (vis) ord = e.emit_ord[tri < 0 ? tri + e.nf : tri];
+    if (vis) ord = e.emit_ord ? e.emit_ord[tri < 0 ? tri + e.nf : tri] : ord_known;
     bool is_area = ord >= 0;
     src = -1;
     if (is_area) {

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -58,6 +59,9 @@ extern "C" IRIS_API int iris_debug_set(const char* key, long long value) {
     return IRIS_OK;
 }
 extern "C" IRIS_API const char* iris_version(void) { return "iris_hip 0.1 (gfx950)"; }
+#ifndef IRIS_NO_FUSED_RECORDS
+#define IRIS_NO_FUSED_RECORDS 0      // (A/B: 1 = the bake kernels keep the plain leaf records and gather the emitter ordinal from its own table)
+#endif
 #ifndef IRIS_BUILD_FLAGS
 #define IRIS_BUILD_FLAGS "unknown"
 #endif
@@ -66,8 +70,10 @@ extern "C" IRIS_API const char* iris_debug_build_flags(void) { return IRIS_BUILD
 // ======================================================================================================
 // handles
 // ======================================================================================================
+static std::atomic<uint64_t> g_scene_uid{1};
 struct iris_scene {
     int device = 0;
+    uint64_t uid = g_scene_uid.fetch_add(1);    // identity of this scene for caches keyed on it (a pointer can be reused after iris_scene_destroy)
     SceneDev dev{};
     void* d_nodes = nullptr;
     void* d_tris = nullptr;
@@ -92,6 +98,11 @@ struct iris_emitter {
     EmitSampleDev sample{};
     bool can_sample = false;
     int64_t n_rad = 0, k = 0;
+    // Fused leaf records (round 5): the scene's leaf-record table with this emitter's ordinal of every triangle in the record's free fourth plane, so that the shading pass of
+    // the bake kernels reads it from the line it fetches anyway.  Built on first use per scene (iris_bake_view), kept for the handle's life (at most two scenes).
+    struct Fused { uint64_t scene_uid; void* d_tris; };
+    mutable std::mutex fused_mu;
+    mutable std::vector<Fused> fused;
 };
 
 // Launches of the one-ray-per-lane kernels (iris_intersect, the path-tracing stages below their tiling threshold) of at most this many rays run in LATENCY MODE
@@ -518,6 +529,7 @@ extern "C" IRIS_API void iris_emitter_destroy(iris_emitter* e) {
     if (!e) return;
     (void)hipFree(e->d_ord); (void)hipFree(e->d_rad); (void)hipFree(e->d_area);
     (void)hipFree(e->d_verts); (void)hipFree(e->d_cdf); (void)hipFree(e->d_ord2tri);
+    for (const auto& f : e->fused) (void)hipFree(f.d_tris);
     delete e;
 }
 
@@ -1000,6 +1012,7 @@ extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int s
     return 256 + blocks * kTileRays * (specular ? 2 : 1) * sizeof(float4) + stack_ovf_bytes();
 }
 
+static const float4* fused_tris(const iris_scene* sc, const iris_emitter* em, hipStream_t st);
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                        const float* wo, float rough, int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id,
                        const int32_t* pix_id, float* out0, float* out1, int64_t* tri_next, int64_t* src_next, uint64_t* stats, int variant,
@@ -1033,6 +1046,7 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         a.scratch = (float4*)((char*)workspace + 256);
         a.stack_ovf = (uint32_t*)((char*)workspace + need - stack_ovf_bytes());
         HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+        if (const float4* ft = fused_tris(sc, em, st)) { a.sc.tris = ft; a.em.emit_ord = nullptr; }      // (tile kernels only: their shading pass reads the ordinal from the record)
         const int64_t n_tiles = (P + tile_px - 1) / tile_px;
         const int grid = (int)std::min<int64_t>(blocks, n_tiles);
 #define IRIS_LAUNCH_BAKE(KERNEL, GRID)                                                                                            \
@@ -1061,6 +1075,28 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
     return IRIS_OK;
 }
 // All lobes of a view in one launch (see bake_view_kernel).  roughness[l] < 0 selects the diffuse lobe.
+__global__ void fuse_ord_kernel(const float4* __restrict__ src, const int32_t* __restrict__ emit_ord, int64_t n_records, float4* __restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_records; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = src[i * 4], y = src[i * 4 + 1], z = src[i * 4 + 2];
+        const int id = __float_as_int(x.w);
+        const int ord = id >= 0 ? emit_ord[id] : -1;              // (the degenerate record unused child slots point to carries id -1)
+        dst[i * 4] = x; dst[i * 4 + 1] = y; dst[i * 4 + 2] = z; dst[i * 4 + 3] = make_float4(__int_as_float(ord), 0.f, 0.f, 0.f);
+    }
+}
+// the scene's leaf records with the emitter's ordinals in the fourth plane; NULL when they cannot be had (memory): the caller then keeps the plain table + the ordinal gather
+static const float4* fused_tris(const iris_scene* sc, const iris_emitter* em, hipStream_t st) {
+    if (IRIS_NO_FUSED_RECORDS) return nullptr;
+    std::lock_guard<std::mutex> lock(em->fused_mu);
+    for (const auto& f : em->fused) if (f.scene_uid == sc->uid) return (const float4*)f.d_tris;
+    if (em->fused.size() >= 2) { (void)hipFree(em->fused.front().d_tris); em->fused.erase(em->fused.begin()); }      // (a training loop uses one scene; keep the handle bounded)
+    void* d = nullptr;
+    const int64_t n_rec = (int64_t)sc->dev.n_tris + 1;
+    if (hipMalloc(&d, (size_t)n_rec * 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    hipLaunchKernelGGL(fuse_ord_kernel, dim3(grid_for(n_rec, 256, 4096)), dim3(256), 0, st, sc->dev.tris, em->dev.emit_ord, n_rec, (float4*)d);
+    if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(d); return nullptr; }       // (once per (scene, emitter): later calls on any stream find it complete)
+    em->fused.push_back({sc->uid, d});
+    return (const float4*)d;
+}
 extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                               const float* wo, const int32_t* pix_id, int64_t P, int n_lobes, const float* roughness, const int32_t* spp,
                               const uint32_t* stream_ids, uint64_t seed, float* const* out0, float* const* out1, void* workspace,
@@ -1075,6 +1111,7 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     if (!workspace || workspace_bytes < need) return fail(IRIS_ERR_ARG, "iris_bake_view: workspace of iris_bake_workspace_bytes() bytes required");
     ViewArgs v{};
     v.base.sc = sc->dev; v.base.em = em->dev; v.base.slf = slf->dev;
+    if (const float4* ft = fused_tris(sc, em, (hipStream_t)stream)) { v.base.sc.tris = ft; v.base.em.emit_ord = nullptr; }      // the shading pass reads the ordinal from the record
     v.base.pos = pos; v.base.nrm = nrm; v.base.wo = wo; v.base.pix_id = pix_id; v.base.P = P; v.base.seed = seed;
     v.base.tile_counter = (unsigned int*)workspace;
     v.base.scratch = (float4*)((char*)workspace + 256);
