@@ -206,13 +206,7 @@ struct SlfDev {
     const float4* radiance;  // kv rows padded to 16 B: one dwordx4 gather per lookup
     int H;
     float vmin, den;         // float32(voxel_min), float32(voxel_max - voxel_min)
-    // Hashed copy for the shading pass of the bake kernels (round 5; NULL: not built): (r, g, b, voxel key) per OCCUPIED voxel, open addressing with linear probing at a
-    // load of at most 1/2 -- ONE scattered 64-B request per lookup (1.2 with the probes that leave the line) where the index grid + the radiance row are two.
-    const float4* hash;
-    uint32_t hash_shift;     // table of 2^(32 - hash_shift) entries; slot of a key = (key * 2654435761) >> hash_shift
 };
-constexpr uint32_t kSlfHashEmpty = 0xFFFFFFFFu;
-__device__ __host__ __forceinline__ uint32_t slf_hash_slot(uint32_t key, uint32_t shift) { return (key * 2654435761u) >> shift; }
 struct EmitDev {
     const int32_t* emit_ord;  // nf: emitter ordinal or -1   (is_emitter + emitter_idx, model/emitter.py:153-162)
     const float4* radiance;   // n_rad rows padded to 16 B, indexed by emitter ordinal (model/emitter.py:203)
@@ -221,9 +215,6 @@ struct EmitDev {
     float emitter_pdf;        // 1/k
 };
 
-#ifndef IRIS_EXP_NOINDS
-#define IRIS_EXP_NOINDS 0
-#endif
 // model/slf.py:41-54 spatial_idx: ((x-vmin)/(vmax-vmin)*H).long().clamp(0,H-1) -> inds[z,y,x]
 __device__ __forceinline__ int voxel_coord(float p, const SlfDev& s) {
     float f = (p - s.vmin) / s.den * (float)s.H;
@@ -233,25 +224,7 @@ __device__ __forceinline__ int voxel_coord(float p, const SlfDev& s) {
 }
 __device__ __forceinline__ int slf_index(const SlfDev& s, f3 p) {
     int cx = voxel_coord(p.x, s), cy = voxel_coord(p.y, s), cz = voxel_coord(p.z, s);
-#if IRIS_EXP_NOINDS
-    // (UPPER-BOUND EXPERIMENT, wrong results: what does the index-grid gather cost?  A row computed from the voxel instead of looked up -- the radiance gather that follows stays
-    //  as scattered as it is; never shipped)
-    return (int)((((uint32_t)cz * (uint32_t)s.H + (uint32_t)cy) * (uint32_t)s.H + (uint32_t)cx) * 2654435761u >> 13);      // < 2^19 rows
-#endif
     return s.inds[((int64_t)cz * s.H + cy) * s.H + cx];
-}
-// model/slf.py:63-70 forward through the hashed copy: the same radiance (the table holds copies of the rows), no row index
-__device__ __forceinline__ f3 slf_forward_hashed(const SlfDev& s, f3 p) {
-    const uint32_t cx = (uint32_t)voxel_coord(p.x, s), cy = (uint32_t)voxel_coord(p.y, s), cz = (uint32_t)voxel_coord(p.z, s);
-    const uint32_t key = (cz * (uint32_t)s.H + cy) * (uint32_t)s.H + cx, mask = 0xFFFFFFFFu >> s.hash_shift;
-    uint32_t h = slf_hash_slot(key, s.hash_shift);
-    for (;;) {
-        const float4 e = s.hash[h];
-        const uint32_t k = __float_as_uint(e.w);
-        if (k == key) return mk3(e.x, e.y, e.z);
-        if (k == kSlfHashEmpty) return mk3(0.f, 0.f, 0.f);           // empty space (model/slf.py:66: inds == -1 -> zero radiance)
-        h = (h + 1u) & mask;
-    }
 }
 // model/slf.py:63-70 forward   (j: the voxel row that was read, -1 = empty space)
 __device__ __forceinline__ f3 slf_forward(const SlfDev& s, f3 p, int& j) {
@@ -283,7 +256,7 @@ __device__ __forceinline__ f3 eval_emitter1(const EmitDev& e, const SlfDev& s, f
     }
     valid_next = (!is_area) && vis;
     if (has_rough && (!is_area) && vis && rough > trace_rough) {
-        f3 d = s.hash ? slf_forward_hashed(s, p) : slf_forward(s, p, src);      // (hash: set by the bake launches that do not report `src`; wave-uniform)
+        f3 d = slf_forward(s, p, src);
         Le = mk3(Le.x + d.x, Le.y + d.y, Le.z + d.z);
         if ((d.x + d.y) + d.z > 0.f) valid_next = false;
     }

@@ -85,12 +85,6 @@ struct iris_slf {
     void* d_inds = nullptr;
     void* d_rad = nullptr;
     int64_t kv = 0;
-    // hashed copy (SlfDev::hash) for the bake kernels' shading pass: built by the first bake call that can use it, kept in step by iris_slf_set_radiance
-    mutable std::mutex hash_mu;
-    mutable void* d_hash = nullptr;       // float4[2^bits]: (r, g, b, voxel key)
-    mutable void* d_hash_pos = nullptr;   // uint32[kv]: the slot of row j's entry (radiance updates)
-    mutable uint32_t hash_shift = 0;
-    mutable bool hash_failed = false;
 };
 struct iris_emitter {
     int device = 0;
@@ -374,7 +368,7 @@ extern "C" IRIS_API int iris_slf_create_dev(const int64_t* inds_dev, int H, cons
 }
 extern "C" IRIS_API void iris_slf_destroy(iris_slf* s) {
     if (!s) return;
-    (void)hipFree(s->d_inds); (void)hipFree(s->d_rad); (void)hipFree(s->d_hash); (void)hipFree(s->d_hash_pos);
+    (void)hipFree(s->d_inds); (void)hipFree(s->d_rad);
     delete s;
 }
 
@@ -543,15 +537,10 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float4* __restric
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = make_float4(src[i * 3], src[i * 3 + 1], src[i * 3 + 2], 0.f);
 }
-__global__ void slf_hash_update_kernel(const float4* __restrict__ radiance, const uint32_t* __restrict__ pos_of_row, int64_t kv, float4* table);
 extern "C" IRIS_API int iris_slf_set_radiance(iris_slf* s, const float* radiance_dev, int64_t kv, iris_stream_t stream) {
     if (!s || kv != s->kv || (kv > 0 && !radiance_dev)) return fail(IRIS_ERR_ARG, "iris_slf_set_radiance: bad arguments");
     if (kv == 0) return IRIS_OK;
     hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(kv, 256, 1024)), dim3(256), 0, (hipStream_t)stream, radiance_dev, (float4*)s->d_rad, kv);
-    {   // the hashed copy of the rows (slf_for_bake) follows, stream-ordered like the rows themselves
-        std::lock_guard<std::mutex> lock(s->hash_mu);
-        if (s->d_hash) hipLaunchKernelGGL(slf_hash_update_kernel, dim3(grid_for(kv, 256, 1024)), dim3(256), 0, (hipStream_t)stream, (const float4*)s->d_rad, (const uint32_t*)s->d_hash_pos, kv, (float4*)s->d_hash);
-    }
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
@@ -1023,57 +1012,6 @@ extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int s
     return 256 + blocks * kTileRays * (specular ? 2 : 1) * sizeof(float4) + stack_ovf_bytes();
 }
 
-// ---- hashed SLF (iris_device.h slf_forward_hashed) ----
-__global__ void slf_hash_fill_kernel(float4* table, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) table[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kSlfHashEmpty));
-}
-__global__ void slf_hash_build_kernel(const int32_t* __restrict__ inds, const float4* __restrict__ radiance, int64_t n_vox, float4* table, uint32_t shift, uint32_t* __restrict__ pos_of_row) {
-    const uint32_t mask = 0xFFFFFFFFu >> shift;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_vox; i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = inds[i];
-        if (j < 0) continue;
-        const uint32_t key = (uint32_t)i;                              // the linear voxel index (z * H + y) * H + x IS the key
-        uint32_t h = slf_hash_slot(key, shift);
-        for (;;) {                                                     // claim the first empty slot of the probe sequence (keys are distinct: one voxel, one row)
-            uint32_t* kw = reinterpret_cast<uint32_t*>(&table[h].w);
-            if (atomicCAS(kw, kSlfHashEmpty, key) == kSlfHashEmpty) break;
-            h = (h + 1u) & mask;
-        }
-        const float4 r = radiance[j];
-        table[h].x = r.x; table[h].y = r.y; table[h].z = r.z;
-        pos_of_row[j] = h;
-    }
-}
-__global__ void slf_hash_update_kernel(const float4* __restrict__ radiance, const uint32_t* __restrict__ pos_of_row, int64_t kv, float4* table) {
-    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < kv; j += (int64_t)gridDim.x * blockDim.x) {
-        const float4 r = radiance[j];
-        float4* e = table + pos_of_row[j];
-        e->x = r.x; e->y = r.y; e->z = r.z;
-    }
-}
-#ifndef IRIS_NO_SLF_HASH
-#define IRIS_NO_SLF_HASH 0      // (A/B: 1 = the shading pass keeps the index grid + radiance row lookups)
-#endif
-// the SlfDev a bake launch shades with: with the hashed copy when it exists or can be built (and the launch does not report table rows), the plain tables otherwise
-static SlfDev slf_for_bake(const iris_slf* s, bool want_rows, hipStream_t st) {
-    SlfDev d = s->dev;
-    d.hash = nullptr; d.hash_shift = 0;
-    if (IRIS_NO_SLF_HASH || want_rows || s->kv <= 0 || (int64_t)s->dev.H * s->dev.H * s->dev.H >= ((int64_t)1 << 32) - 1) return d;
-    std::lock_guard<std::mutex> lock(s->hash_mu);
-    if (!s->d_hash && !s->hash_failed) {
-        uint32_t bits = 4;
-        while (((int64_t)1 << bits) < 2 * s->kv) ++bits;              // load <= 1/2
-        const int64_t n = (int64_t)1 << bits, n_vox = (int64_t)s->dev.H * s->dev.H * s->dev.H;
-        void *t = nullptr, *p = nullptr;
-        if (hipMalloc(&t, (size_t)n * 16) != hipSuccess || hipMalloc(&p, (size_t)s->kv * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); s->hash_failed = true; return d; }
-        hipLaunchKernelGGL(slf_hash_fill_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, (float4*)t, n);
-        hipLaunchKernelGGL(slf_hash_build_kernel, dim3(grid_for(n_vox, 256, 8192)), dim3(256), 0, st, s->dev.inds, s->dev.radiance, n_vox, (float4*)t, 32u - bits, (uint32_t*)p);
-        if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(t); (void)hipFree(p); s->hash_failed = true; return d; }      // (once per handle: later calls on any stream find it complete)
-        s->d_hash = t; s->d_hash_pos = p; s->hash_shift = 32u - bits;
-    }
-    if (s->d_hash) { d.hash = (const float4*)s->d_hash; d.hash_shift = s->hash_shift; }
-    return d;
-}
 static const float4* fused_tris(const iris_scene* sc, const iris_emitter* em, hipStream_t st);
 static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                        const float* wo, float rough, int64_t P, int spp, const float* u2, uint64_t seed, uint32_t stream_id,
@@ -1109,7 +1047,6 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         a.stack_ovf = (uint32_t*)((char*)workspace + need - stack_ovf_bytes());
         HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
         if (const float4* ft = fused_tris(sc, em, st)) { a.sc.tris = ft; a.em.emit_ord = nullptr; }      // (tile kernels only: their shading pass reads the ordinal from the record)
-        a.slf = slf_for_bake(slf, src_next != nullptr, st);                                                //  ... and the radiance through the hashed copy of the SLF)
         const int64_t n_tiles = (P + tile_px - 1) / tile_px;
         const int grid = (int)std::min<int64_t>(blocks, n_tiles);
 #define IRIS_LAUNCH_BAKE(KERNEL, GRID)                                                                                            \
@@ -1175,7 +1112,6 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     ViewArgs v{};
     v.base.sc = sc->dev; v.base.em = em->dev; v.base.slf = slf->dev;
     if (const float4* ft = fused_tris(sc, em, (hipStream_t)stream)) { v.base.sc.tris = ft; v.base.em.emit_ord = nullptr; }      // the shading pass reads the ordinal from the record
-    v.base.slf = slf_for_bake(slf, false, (hipStream_t)stream);                                                                   // ... and the radiance through the hashed copy of the SLF
     v.base.pos = pos; v.base.nrm = nrm; v.base.wo = wo; v.base.pix_id = pix_id; v.base.P = P; v.base.seed = seed;
     v.base.tile_counter = (unsigned int*)workspace;
     v.base.scratch = (float4*)((char*)workspace + 256);
