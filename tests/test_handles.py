@@ -102,3 +102,39 @@ def test_index_less_device_is_the_current_device(dev, room_setup):
     s["em"].refresh()
     s["em"].handle(cur)                                   # tables built for the index-less device
     assert torch.equal(bs.bake_diffuse(sc, s["em"], pos.to(cur), nrm.to(cur), 64, seed=5), base)
+
+
+def test_fused_leaf_records_follow_scene_and_emitter(dev, room_setup, tmp_path):
+    """The tile / view bake kernels shade from a copy of the scene's leaf records that carries the EMITTER's ordinal per triangle (iris_hip.hip fused_tris), cached in the
+    emitter handle per scene (at most two).  One emitter used with three scenes of the same mesh size in turn (the third evicts the first), a second emitter with other
+    emitter triangles on the same scene, and the first pair again: every bake must equal the bake of the pixel-per-wave kernel, which gathers the ordinal from its table."""
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    from iris_amd.model.emitter import SLFEmitter
+    from iris_amd.utils.path_tracing import Scene
+    from test_hip_parity import _emitter_files
+    from tools import synth
+    s = room_setup
+    r = s["room"]
+    P = 400
+    pos, nrm = T(s["pos"][:P], dev), T(s["nrm"][:P], dev)
+    verts = r["vertices"]
+    scenes = [s["sc"]] + [Scene(verts + np.float32(1e-3 * k), r["faces"], device=dev) for k in (1, 2)]        # three scenes, the same topology
+    # a second emitter: other triangles emit
+    is_em2 = np.zeros_like(r["is_emitter"]); is_em2[::997] = True
+    e2 = synth.emitters_for(verts, r["faces"], is_em2)
+    sl = synth.slf_for(verts, r["faces"], 64)
+    ep, sp = _emitter_files(tmp_path, e2["is_emitter"], e2["emitter_area"], e2["emitter_radiance"], sl["mask"], sl["inds"], sl["radiance"], sl["voxel_min"], sl["voxel_max"])
+    em2 = SLFEmitter(ep, sp)
+
+    def both(sc, em):
+        a = bs.bake_diffuse(sc, em, pos, nrm, 64, seed=3, variant=L.BAKE_TILE_SORTED)
+        b = bs.bake_diffuse(sc, em, pos, nrm, 64, seed=3, variant=L.BAKE_PIXEL_PER_WAVE)
+        assert torch.equal(a, b)
+        return a
+    first = both(scenes[0], s["em"])
+    for sc in scenes[1:] + scenes[:1]:
+        both(sc, s["em"])
+    other = both(scenes[0], em2)
+    assert not torch.equal(other, first)                       # (other emitters, another SLF: another image)
+    assert torch.equal(both(scenes[0], s["em"]), first)
