@@ -204,6 +204,9 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 #ifndef IRIS_TILE_WAVES          // resident waves per SIMD the tile kernels are compiled for (= workgroups per CU): 7 x 20 488 B of LDS, 72 VGPRs.
 #define IRIS_TILE_WAVES 7        // Measured: 6 waves (80 VGPRs) 7.11, 7 waves 7.24, 8 waves (64 VGPRs, 9-entry stacks) 7.17 Grays/s  (LDS now 7 x 22 536 B: 12-entry stacks)
 #endif
+#ifndef IRIS_RESOLVE_AT_RETIRE       // (A/B: 0 = a retiring ray parks (u, v, leaf slot) and the shading pass reads the triangle's record)
+#define IRIS_RESOLVE_AT_RETIRE 1
+#endif
 #ifndef IRIS_TILE_STACK          // per-lane LDS stack entries of the tile kernels; deeper entries go to the workgroup's slab in the workspace
 #define IRIS_TILE_STACK 12       // (a.stack_ovf), NOT to private scratch: without a scratch-resident stack array the kernel fits 6 (7) waves/SIMD (measured +6.5 %)
 #endif
@@ -213,7 +216,11 @@ __global__ __launch_bounds__(kBlock) void bake_kernel(BakeArgs a) {
 //   two uses are separated by workgroup barriers) + *s_chunk (cursor into the sorted list).
 //   res: the workgroup's slab of per-ray slots in the workspace: float4 res[kTileRays], then (specular) float2 res_g[kTileRays].
 //   Slot life: phase A parks the sampled direction (res = wi) and the GGX weights (res_g = g1, g0); phase C replaces res by the
-//   hit (u, v, leaf slot); phase D shades and sums.
+//   hit; phase D shades and sums.  The hit is parked RESOLVED when the records are the fused ones (iris_hip.hip fused_tris) and the
+//   caller does not ask for per-sample triangle ids: a retiring lane re-reads its hit triangle's record -- a line its own traversal
+//   fetched a few iterations ago, where the shading pass a millisecond later would find it evicted -- and parks (hit position, emitter
+//   ordinal | -2 for a miss); otherwise (u, v, leaf slot).  Same hit_position(), same bits.  Round 5: +1.3 % with the shading pass taking
+//   two rounds of a pixel side by side (EXPERIMENTS.md).
 //   The slots are only ever exchanged between waves of THIS workgroup, so __syncthreads() orders them (the waves of a workgroup
 //   share their CU's write-through L1; an agent-scope __threadfence() here flushes that L1 -- including the hot upper BVH levels --
 //   once per tile and was measured 9 % slower per fence pair).
@@ -228,6 +235,9 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
     const int sub = lane / lpp, sl = lane - sub * lpp;
     const float inv_spp = 1.0f / (float)spp;
     const int nr = np * spp;
+#if IRIS_RESOLVE_AT_RETIRE
+    const bool resolve = !a.em.emit_ord && !a.tri_next;      // fused records, and nobody asks for the per-sample triangle ids
+#endif
 
     // r / spp for a tile-local ray index without the 25-instruction integer division: exact for r * spp < 2^32 (r < kTileRays, spp <= kTileRays)
     const uint32_t spp_m = spp > 1 ? (uint32_t)(0x100000000ull / (uint64_t)(uint32_t)spp) + 1u : 0u;
@@ -280,7 +290,23 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
         },
         // position + RayEpsilon*wi (bake_shading.py:117, :180)
         [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); },
-        [&](int r, const Hit& h) { res[r] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f); if (COUNT) n_rays++; });   // every ray retires once
+        [&](int r, const Hit& h) {
+#if IRIS_RESOLVE_AT_RETIRE
+            if (resolve) {
+                // the hit is resolved while its record is still near: position + emitter ordinal instead of (u, v, leaf slot); w = -2: a miss
+                float4 q = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
+                if (h.slot >= 0) {
+                    const float4* tr = a.sc.tris + (int64_t)h.slot * 4;
+                    const float4 tx = tr[0], ty = tr[1], tz = tr[2];
+                    const float ow = tr[3].x;
+                    const f3 pn = hit_position(h, mk3(tx.x, ty.x, tz.x), mk3(tx.y, ty.y, tz.y), mk3(tx.z, ty.z, tz.z));
+                    q = make_float4(pn.x, pn.y, pn.z, ow);
+                }
+                res[r] = q;
+            } else
+#endif
+            res[r] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f);
+            if (COUNT) n_rays++; });   // every ray retires once
 
     // ---- phase D: shade every sample (hit -> p_next -> eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0),
     // bake_shading.py:121-122, :184-185 -> Le * g) and take the per-pixel mean in the fixed order of the pixel-per-wave kernel
@@ -291,6 +317,41 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
         const int pl = g * ppw + sub;
         const bool pvalid = pl < np;
         float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+#if IRIS_RESOLVE_AT_RETIRE
+        // Resolved slots (position + emitter ordinal): what is left of eval_emitter is a chain of three dependent loads per sample -- slot -> voxel index -> radiance row --
+        // with four live registers per sample in flight, so TWO rounds of a pixel run side by side, stage by stage (the sums take them in the order of the plain loop).
+        if (resolve) {
+            for (int rr = 0; rr < rounds; rr += 2) {
+                const int s0 = rr * 64 + sl, s1 = s0 + 64;
+                const bool ok0 = pvalid && s0 < spp, ok1 = pvalid && rr + 1 < rounds && s1 < spp;
+                float4 q0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-2)), q1 = q0;
+                float2 w0 = make_float2(0.f, 0.f), w1 = w0;
+                if (ok0) { q0 = res[pl * spp + s0]; if (SPEC) w0 = res_g[pl * spp + s0]; }
+                if (ok1) { q1 = res[pl * spp + s1]; if (SPEC) w1 = res_g[pl * spp + s1]; }
+                const int o0 = __float_as_int(q0.w), o1 = __float_as_int(q1.w);          // -2 miss, -1 a surface, >= 0 an emitter
+                int j0 = -1, j1 = -1;
+                if (o0 == -1) j0 = slf_index(a.slf, mk3(q0.x, q0.y, q0.z));
+                if (o1 == -1) j1 = slf_index(a.slf, mk3(q1.x, q1.y, q1.z));
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+                if (o0 >= 0 || j0 >= 0) r0 = *(o0 >= 0 ? a.em.radiance + o0 : a.slf.radiance + j0);
+                if (o1 >= 0 || j1 >= 0) r1 = *(o1 >= 0 ? a.em.radiance + o1 : a.slf.radiance + j1);
+                if (ok0) {
+                    const float z = o0 >= 0 ? -0.f : 0.f;                                  // (eval_emitter1: the cache's radiance is ADDED to a zero, the emitter's is taken)
+                    const f3 Le = mk3(z + r0.x, z + r0.y, z + r0.z);
+                    if (a.src_next) a.src_next[(p0 + pl) * spp + s0] = o0 >= 0 ? -2 - o0 : j0;
+                    if (SPEC) { a0x += Le.x * w0.y; a0y += Le.y * w0.y; a0z += Le.z * w0.y; a1x += Le.x * w0.x; a1y += Le.y * w0.x; a1z += Le.z * w0.x; }
+                    else { a0x += Le.x; a0y += Le.y; a0z += Le.z; }
+                }
+                if (ok1) {
+                    const float z = o1 >= 0 ? -0.f : 0.f;
+                    const f3 Le = mk3(z + r1.x, z + r1.y, z + r1.z);
+                    if (a.src_next) a.src_next[(p0 + pl) * spp + s1] = o1 >= 0 ? -2 - o1 : j1;
+                    if (SPEC) { a0x += Le.x * w1.y; a0y += Le.y * w1.y; a0z += Le.z * w1.y; a1x += Le.x * w1.x; a1y += Le.y * w1.x; a1z += Le.z * w1.x; }
+                    else { a0x += Le.x; a0y += Le.y; a0z += Le.z; }
+                }
+            }
+        } else
+#endif
         for (int rr = 0; rr < rounds; ++rr) {
             const int s = rr * 64 + sl;
             if (pvalid && s < spp) {

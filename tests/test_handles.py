@@ -138,3 +138,31 @@ def test_fused_leaf_records_follow_scene_and_emitter(dev, room_setup, tmp_path):
     other = both(scenes[0], em2)
     assert not torch.equal(other, first)                       # (other emitters, another SLF: another image)
     assert torch.equal(both(scenes[0], s["em"]), first)
+
+
+def test_resolved_and_plain_hit_slots_give_the_same_maps(dev, room_setup):
+    """The tile / view kernels park a finished ray's hit RESOLVED (position + emitter ordinal, iris_bake.h tile_body) unless the caller asks for the per-sample triangle
+    ids, which need the plain (u, v, leaf slot) form: both forms through the same shading pass must give the same bits -- maps and per-sample table rows -- on the diffuse
+    lobe and on a specular one."""
+    from iris_amd import _lib as L
+    from iris_amd import bake_shading as bs
+    s = room_setup
+    P = 700
+    pos, nrm, wo = T(s["pos"][:P], dev), T(s["nrm"][:P], dev), T(s["wo"][:P], dev)
+    for variant in (L.BAKE_TILE_SORTED,):
+        Ld_r, src_r = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 128, seed=9, want_src=True, variant=variant)
+        Ld_p, tri_p, src_p = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 128, seed=9, want_tri=True, want_src=True, variant=variant)
+        assert torch.equal(Ld_r, Ld_p) and torch.equal(src_r, src_p)
+        assert int((tri_p >= 0).sum()) > 0.9 * tri_p.numel() and int((src_p <= -2).sum()) > 0          # hits, some of them on emitters
+        a0, a1, asrc = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 0.3, 96, seed=9, want_src=True, variant=variant)       # (96: a ragged second round)
+        b0, b1, _, bsrc = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 0.3, 96, seed=9, want_tri=True, want_src=True, variant=variant)
+        assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(asrc, bsrc)
+    # the fused view kernel (all lobes behind one launch) takes the resolved form; the lobes baked one by one with triangle ids the plain one
+    rough = bs.roughness_levels().tolist()
+    lobes = [None, rough[0], rough[3]]
+    view = bs.bake_lobes(s["sc"], s["em"], pos, nrm, wo, lobes, [64, 64, 64], seed=4, stream_ids=[0, 1, 4])
+    Ld, _ = bs.bake_diffuse(s["sc"], s["em"], pos, nrm, 64, seed=4, stream_id=0, want_tri=True)
+    assert torch.equal(view[0], Ld)
+    for l, sid in ((1, 1), (2, 4)):
+        c0, c1, _ = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, lobes[l], 64, seed=4, stream_id=sid, want_tri=True)
+        assert torch.equal(view[l][0], c0) and torch.equal(view[l][1], c1)
