@@ -157,9 +157,9 @@ def test_resolved_and_plain_hit_slots_give_the_same_maps(dev, room_setup):
         a0, a1, asrc = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 0.3, 96, seed=9, want_src=True, variant=variant)       # (96: a ragged second round)
         b0, b1, _, bsrc = bs.bake_specular(s["sc"], s["em"], pos, nrm, wo, 0.3, 96, seed=9, want_tri=True, want_src=True, variant=variant)
         assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(asrc, bsrc)
-    # other reduce geometries: several pixels per wave (spp 16), an odd number of rounds (192 = 3 x 64), a ragged fifth round (300)
-    for spp in (16, 192, 300):
-        p2, n2 = pos[:200].contiguous(), nrm[:200].contiguous()
+    # other reduce geometries: one sample, several pixels per wave (spp 3, 16), an odd number of rounds (192 = 3 x 64), a ragged fifth round (300), a tile of one pixel (5000)
+    for spp, n_px in ((1, 1), (1, 67), (3, 5), (16, 200), (192, 200), (300, 200), (5000, 3)):
+        p2, n2 = pos[:n_px].contiguous(), nrm[:n_px].contiguous()
         Ld_r = bs.bake_diffuse(s["sc"], s["em"], p2, n2, spp, seed=spp, variant=L.BAKE_TILE_SORTED)
         Ld_p, _ = bs.bake_diffuse(s["sc"], s["em"], p2, n2, spp, seed=spp, want_tri=True, variant=L.BAKE_TILE_SORTED)
         assert torch.equal(Ld_r, Ld_p), spp
