@@ -52,6 +52,9 @@ IRIS_API int iris_debug_set(const char *key, long long value);
 IRIS_API int iris_debug_ngp_encode(const iris_ngp *, const float *position, int64_t N, uint32_t *feat, iris_stream_t);
 /* The compiler flags this library was built with (iris_amd/csrc/Makefile embeds them): part of the stamp that ties a counter profile to a build. */
 IRIS_API const char *iris_debug_build_flags(void);
+/* sha256 (16 hex digits) over EVERY file this library was compiled from (kernels of all stages, host code, ABI headers), taken by the Makefile at build
+ * time: identifies the arithmetic of the loaded binary without looking at the sources on disk ("unknown" for a build that did not go through the Makefile). */
+IRIS_API const char *iris_debug_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "iris_debug_bake_specular": [_P, _P, _P, _P, _P, _P, _F, _I64, _I32, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _I32, _P, _U64, _P],
     "iris_debug_set": [C.c_char_p, C.c_longlong],
     "iris_debug_build_flags": [],
+    "iris_debug_source_hash": [],
     "iris_bake_view": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _U64, _P, _P, _P, _U64, _P],
     "iris_lerp_specular": [_P, _P, _I64, _I32, _P, _P],
     "iris_unstripe_maps": [_P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P],
@@ -91,7 +92,7 @@ PROTOTYPES = {
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_ngp_n_params": C.c_int64, "iris_ngp_destroy": None, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_debug_source_hash": C.c_char_p, "iris_ngp_n_params": C.c_int64, "iris_ngp_destroy": None, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
 
 _lib = None
 
@@ -140,9 +141,14 @@ def device_index(device):
 
 
 def build_id():
-    """What identifies the ARITHMETIC of the loaded library for a resumable run: its version string, the compiler flags embedded in it and the hash of the
-    kernel sources it was built from (a sampler or traversal change alters bits: maps of two builds must not be mixed by --resume)."""
-    return lib().iris_version().decode() + "|" + lib().iris_debug_build_flags().decode() + "|" + source_hash()
+    """What identifies the ARITHMETIC of the LOADED library for a resumable run: its version string, the compiler flags and the hash of ALL the sources it was
+    compiled from -- path-tracing stages, material network, shading cache and denoiser included --, both embedded in the binary by the Makefile (a sampler,
+    traversal, network or filter change alters bits: maps of two builds must not be mixed by --resume).  Nothing is read from csrc/ on disk: a stale library
+    keeps its own id, an installation without sources works.  A library built around the Makefile carries no hash and is refused."""
+    h = lib().iris_debug_source_hash().decode()
+    if h == "unknown" or len(h) != 16:
+        raise IrisError("libiris_hip.so carries no source hash (built without iris_amd/csrc/Makefile): a resumable run cannot be keyed on it")
+    return lib().iris_version().decode() + "|" + lib().iris_debug_build_flags().decode() + "|" + h
 
 
 class StageTimer:

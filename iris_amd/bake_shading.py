@@ -344,7 +344,7 @@ def main(argv=None):
     parser.add_argument("--ldr_img_dir", type=str, default=None)       # accepted for compatibility; bake never reads images
     parser.add_argument("--res_scale", type=float, default=1.0)
     # additions (defaults reproduce the reference)
-    parser.add_argument("--cameras", type=str, default=None, help="generic camera JSON (required for scannetpp: COLMAP I/O is out of scope)")
+    parser.add_argument("--cameras", type=str, default=None, help="generic camera JSON instead of the dataset's own camera files")
     parser.add_argument("--img_hw", type=int, nargs=2, default=None)
     parser.add_argument("--spp_diffuse", type=int, default=SPP_DIFFUSE)
     parser.add_argument("--spps_specular", type=int, nargs=N_ROUGHNESS, default=SPPS_SPECULAR)
@@ -378,8 +378,10 @@ def main(argv=None):
         img_hw, views = cameras.load_synthetic(args.scene, args.res_scale, hw)
     elif args.dataset == "real":
         img_hw, views = cameras.load_real(args.scene, args.res_scale, hw)
+    elif args.dataset == "scannetpp":                      # Scannetpp(args.dataset_root, args.scene, split='train', pixel=False, res_scale=args.res_scale)
+        img_hw, views = cameras.load_scannetpp(args.dataset_root, args.scene, args.res_scale)
     else:
-        raise L.IrisError("--dataset scannetpp needs --cameras cameras.json (COLMAP / nerfstudio parsing is dataset I/O outside this path)")
+        raise L.IrisError("--dataset {!r}: synthetic | real | scannetpp, or --cameras cameras.json".format(args.dataset))
 
     emitter = SLFEmitter(args.emitter_path, args.slf_path)
     for p in emitter.parameters():

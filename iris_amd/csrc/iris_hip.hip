@@ -66,6 +66,10 @@ extern "C" IRIS_API const char* iris_version(void) { return "iris_hip 0.1 (gfx95
 #define IRIS_BUILD_FLAGS "unknown"
 #endif
 extern "C" IRIS_API const char* iris_debug_build_flags(void) { return IRIS_BUILD_FLAGS; }
+#ifndef IRIS_SOURCE_HASH
+#define IRIS_SOURCE_HASH "unknown"
+#endif
+extern "C" IRIS_API const char* iris_debug_source_hash(void) { return IRIS_SOURCE_HASH; }
 
 // ======================================================================================================
 // handles

@@ -3,8 +3,9 @@
 Only the pose / intrinsics part of the reference's dataset classes is needed by bake_shading (images are never read there):
   synthetic : {scene}/train/transforms.json, focal = 0.5 w / tan(0.5 camera_angle_x)          (utils/dataset/synthetic_ldr.py:129-150)
   real      : {scene}/cam.txt (origin, lookat, up per view) + K_list.txt, train split          (utils/dataset/real_ldr.py:25-34,85-166)
-  generic   : a JSON file {"img_hw":[H,W], "views":[{"K":3x3, "c2w":3x4}, ...]} (OpenCV convention) -- also the way to feed
-              ScanNet++ cameras, whose COLMAP / nerfstudio loaders are dataset I/O outside this path's scope.
+  scannetpp : {dataset_root}/data/{scene}/psdf/train_test_lists.json + transforms_all.json (nerfstudio layout: one shared
+              fl_x fl_y cx cy h w, per frame an OpenGL camera-to-world), train split                 (utils/dataset/scannetpp/dataset.py:78-141)
+  generic   : a JSON file {"img_hw":[H,W], "views":[{"K":3x3, "c2w":3x4}, ...]} (OpenCV convention)
 """
 import json
 import os
@@ -53,6 +54,39 @@ def load_real(scene_dir, res_scale=1.0, img_hw=None, split="train"):
         R = np.stack((np.cross(-up, at), -up, at), -1).astype(np.float32)   # OpenGL (origin, lookat, up) -> OpenCV c2w
         K = K.copy(); K[:2, :] *= res_scale
         views.append({"kind": "real", "K": K.astype(np.float32), "c2w": np.hstack((R, origin.reshape(3, 1))).astype(np.float32)})
+    return img_hw, views
+
+
+def load_scannetpp(dataset_root, scene_id, res_scale=1.0, split="train"):
+    """The pose list of the reference's ``Scannetpp(dataset_root, scene_id, split, pixel=False, res_scale)`` (utils/dataset/scannetpp/dataset.py:78-141;
+    built at bake_shading.py:68, refine_shading.py:73, slf_bake.py:62): image size ``(int(h*s), int(w*s))``; ONE intrinsic matrix for every view, its first
+    two rows scaled by ``s`` (formed in double, rounded to f32 once, as ``torch.tensor(Ks).float()``); per frame of ``transforms_all.json`` whose file name
+    is in the split's list, the 4x4 ``transform_matrix`` with its y and z camera axes negated (OpenGL -> OpenCV) and the top three rows kept; views ordered
+    by the position of their name in the split's list (frames not in it are skipped; a listed name without a frame has no view).  The images under
+    ``psdf/images`` are never opened: the bake does not use them."""
+    root = os.path.join(dataset_root, "data", scene_id, "psdf")
+    with open(os.path.join(root, "train_test_lists.json")) as fh:
+        lists = json.load(fh)
+    names = lists["train"] if split == "train" else lists["test"] if split == "test" else lists["train"] + lists["test"]
+    with open(os.path.join(root, "transforms_all.json")) as fh:
+        meta = json.load(fh)
+    img_hw = (int(meta["h"] * res_scale), int(meta["w"] * res_scale))
+    K = np.array([[meta["fl_x"], 0, meta["cx"]], [0, meta["fl_y"], meta["cy"]], [0, 0, 1]], dtype=np.float64)
+    K[:2] *= res_scale
+    K = K.astype(np.float32)
+    first = {}
+    for i, n in enumerate(names):                                      # list.index(): the FIRST position of a name
+        first.setdefault(n, i)
+    found = []
+    for frame in meta["frames"]:
+        name = frame["file_path"].split("/")[-1]
+        if name not in first:
+            continue
+        c2w = np.array(frame["transform_matrix"], dtype=np.float64)
+        c2w[:3, 1:3] *= -1
+        found.append((first[name], c2w[:3].astype(np.float32)))
+    order = np.argsort(np.array([i for i, _ in found], dtype=np.int64)) if found else []   # the reference's np.argsort(ids)
+    views = [{"kind": "real", "K": K.copy(), "c2w": found[j][1], "name": names[found[j][0]]} for j in order]
     return img_hw, views
 
 

@@ -60,3 +60,28 @@ def test_no_cpu_fallback():
                 txt = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
                 assert "iris_oracle" not in txt or "oracle/iris_oracle.c" in txt, f
+
+
+def test_build_id_comes_from_the_loaded_binary_and_covers_every_source():
+    """refine_shading --resume keys on L.build_id(): the hash the Makefile embedded in the library, over ALL the files the library is compiled from
+    (the path-tracing stages, the material network, the shading cache and the denoiser included -- their arithmetic decides the refined maps), not a
+    hash of whatever lies in csrc/ at run time."""
+    import hashlib
+    from iris_amd import _lib as L
+    csrc = os.path.join(REPO, "iris_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    listed = re.search(r"^SOURCES\s*=\s*(.+)$", mk, re.M).group(1).split()
+    on_disk = {f for f in os.listdir(csrc) if f.endswith((".h", ".hip", ".cpp"))}
+    assert {os.path.basename(f) for f in listed if not f.startswith("..")} == on_disk, "a source file is missing from the Makefile's SOURCES (and from the hash)"
+    hip = open(os.path.join(csrc, "iris_hip.hip")).read() + open(os.path.join(csrc, "iris_bake.h")).read() + open(os.path.join(csrc, "iris_pt.h")).read()
+    for inc in set(re.findall(r'#include "(\w+\.h)"', hip)):
+        assert inc in {os.path.basename(f) for f in listed}, inc
+    h = hashlib.sha256()
+    for f in listed:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    embedded = L.lib().iris_debug_source_hash().decode()
+    assert embedded == h.hexdigest()[:16], "libiris_hip.so is older than its sources: rebuild (make -C iris_amd/csrc)"
+    assert L.build_id().endswith("|" + embedded) and L.lib().iris_debug_build_flags().decode() in L.build_id()
+    src = open(os.path.join(REPO, "iris_amd", "_lib.py")).read()
+    body = src[src.index("def build_id"):src.index("class StageTimer")]
+    assert "open(" not in body and not re.search(r"(?<!debug_)source_hash\(\)", body)          # nothing read from disk

@@ -39,10 +39,10 @@ class Fixture:
     """the reference's tensors rebuilt from the fixture + the oracle (every array verified against its stored sha256)"""
 
     def __init__(self, oracle_mod):
-        import make_cfg2_golden as mc
+        import golden_codec as mc
         self.mc, self.o = mc, oracle_mod
         g = self.g = golden("bake_cfg2_reference.npz")
-        self.room, self.slf_np, self.emi_np, K, c2w = mc.workload()
+        self.room, self.slf_np, self.emi_np, K, c2w = mc.workload(mc.CFG2)
         assert np.array_equal(K, g["K"]) and np.array_equal(c2w, g["c2w"])
         self.H, self.W, self.spp, self.P, self.seed = int(g["H"]), int(g["W"]), int(g["spp"]), int(g["P"]), int(g["seed"])
         self.osc = oracle_mod.Scene(self.room["vertices"], self.room["faces"])

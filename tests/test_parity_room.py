@@ -33,9 +33,9 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 
 
 def _fixture():
-    import make_room_golden as mg
+    import golden_codec as mg
     g = golden("bake_room.npz")
-    room, slf_np, emi_np, K, c2w = mg.workload()
+    room, slf_np, emi_np, K, c2w = mg.workload(mg.ROOM)
     assert np.array_equal(K, g["K"]) and np.array_equal(c2w, g["c2w"])
     return mg, g, room, slf_np, emi_np, K, c2w
 

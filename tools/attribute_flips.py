@@ -12,12 +12,12 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 import oracle                      # noqa: E402
-import make_room_golden as mg      # noqa: E402
+import golden_codec as mg      # noqa: E402
 
 
 def main():
     g = np.load(os.path.join(REPO, "tests", "golden", "bake_room.npz"))
-    room, slf_np, emi_np, K, c2w = mg.workload()
+    room, slf_np, emi_np, K, c2w = mg.workload(mg.ROOM)
     osc = oracle.Scene(room["vertices"], room["faces"])
     oslf = oracle.VoxelSLF(slf_np["inds"], slf_np["radiance"], slf_np["voxel_min"], slf_np["voxel_max"])
     oem = oracle.SLFEmitter(emi_np["is_emitter"], emi_np["emitter_radiance"], emi_np["emitter_area"], oslf)
