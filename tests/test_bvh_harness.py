@@ -63,3 +63,28 @@ def test_node_visit_instruction_counts():
     assert b8["vector_loads"] == 7 and b8["v_fma_mix_f32"] == 48 and b8["scratch"] == 0
     assert b8["vector_alu"] > 1.7 * b4["vector_alu"]                                          # what decided against the per-lane BVH8: 16.6 x 176 > 24.2 x 91
     assert b8["vgprs_of_the_bare_loop"] > b4["vgprs_of_the_bare_loop"] + 15
+
+
+@pytest.mark.timeout(900)
+def test_wave_schedule_simulator(tmp_path, oracle_mod):
+    """tools/bvh_eval/wavesim (round 6: ray reordering across tiles decided on the host): trace_stream's wave-level schedule replayed on the kernel's own rays.  On a small room:
+    the shipped scheme's lane utilisation is where the instrumented GPU launches put it (0.5-0.7), one sort over a window of 8 tiles with finer direction cells raises it --
+    but not to the 0.72 the verdict of round 5 set as the bar for building it --, and parking a leaf to go on with the node phase only adds visits."""
+    exe = str(tmp_path / "wavesim")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "iris_amd", "csrc"), os.path.join(BVH_EVAL, "wavesim.cpp"),
+                    os.path.join(REPO, "iris_amd", "csrc", "bvh_build.cpp"), "-lpthread", "-o", exe], check=True, timeout=600)
+    room, rays = str(tmp_path / "room.bin"), str(tmp_path / "block.bin")
+    subprocess.run([sys.executable, os.path.join(BVH_EVAL, "dump_room.py"), room, "0", "60000"], check=True, timeout=600, cwd=REPO)
+    subprocess.run([sys.executable, os.path.join(BVH_EVAL, "dump_block_rays.py"), rays, "16", "2", "0,6", "0", "60000", "128"], check=True, timeout=600, cwd=REPO)
+    out = subprocess.run([exe, room, rays, "tile", "win:16:16:16:16:0:0:d", "pend+tile"], check=True, capture_output=True, text=True, timeout=600).stdout
+    rows = {(r["scheme"], r["lobe"]): r for r in map(json.loads, out.strip().splitlines())}
+    for lobe in (0, 6):
+        t, w, p = rows[("tile", lobe)], rows[("win:16:16:16:16:0:0:d", lobe)], rows[("pend+tile", lobe)]
+        assert t["rays"] == w["rays"] == p["rays"] == 2 * 16 * 16 * 128
+        assert t["node_visits_per_ray"] == w["node_visits_per_ray"] and t["tri_tests_per_ray"] == w["tri_tests_per_ray"]      # the order of the rays changes no ray's work
+        assert 0.45 < t["node_step_lane_util"] < 0.75 and 0.4 < t["leaf_step_lane_util"] < 0.75
+        assert t["node_step_lane_util"] < w["node_step_lane_util"] < 0.72
+        assert w["modelled_traversal_vector_instructions_per_ray"] < t["modelled_traversal_vector_instructions_per_ray"]
+        assert p["node_visits_per_ray"] > t["node_visits_per_ray"]
+        total = t["node_step_lane_util"] + t["node_step_lanes_waiting_at_a_leaf"] + t["node_step_lanes_idle"] + t["node_step_lanes_sitting_out_a_shared_step"]
+        assert abs(total - 1.0) < 1e-3                                                                                         # every lane of every node step is accounted for
