@@ -90,11 +90,12 @@ struct Stats {
 };
 
 struct Wave {
-    Lane l[64]; bool more = true, done = false; int shared_tries = kSharedTries; int phase = 0;   // 0 top, 1 node, 2 leaf
+    Lane l[64]; std::vector<Lane> own; bool more = true, done = false; int shared_tries = kSharedTries; int phase = 0;   // 0 top, 1 node, 2 leaf
 };
 
 struct Sim {
-    const Scene& sc; Stats st; bool postpone = false;   // postpone: a lane that reaches a leaf in the node phase parks it (one per lane) and goes on with its stack until the phase ends
+    const Scene& sc; Stats st; int parking = 0; int pool_take = 64; int park_max_sp = 12; std::vector<Lane> pool;   // parking: 0 off, 1 one pool per workgroup, 2 one pool per WAVE (no exchange between waves)
+     long long parked = 0, pool_waves = 0; bool postpone = false;   // postpone: a lane that reaches a leaf in the node phase parks it (one per lane) and goes on with its stack until the phase ends
     explicit Sim(const Scene& s) : sc(s) {}
 
     void begin(Lane& L, const Ray& r) {
@@ -154,6 +155,19 @@ struct Sim {
                 bool stepped = false;
                 if (w.more && (n_idle >= kRefillMin || n_idle == 64)) {
                     bool any = false;
+                    if (parking) {
+                        // PARKING (round 6 study): a refilling wave hands the rays it still carries to a pool and starts 64 fresh rays together; when the pool holds a
+                        // wave's worth, a refilling wave takes those instead (the stragglers run with each other); nothing is parked once the list is exhausted;
+                        // a ray whose stack has entries beyond the LDS part stays where it is
+                        std::vector<Lane>& pl = parking == 2 ? w.own : pool;
+                        if (cursor < list.size()) for (auto& L : w.l) if (!is_idle(L) && L.sp <= park_max_sp) { pl.push_back(L); ++parked; L.cur = kEmpty; L.pend = kEmpty; }
+                        const bool from_pool = (int)pl.size() >= pool_take || cursor >= list.size();
+                        if (from_pool && !pl.empty()) ++pool_waves;
+                        for (auto& L : w.l) if (is_idle(L)) {
+                            if (from_pool) { if (!pl.empty()) { L = pl.back(); pl.pop_back(); any = true; } }
+                            else if (cursor < list.size()) { begin(L, rays[list[cursor++]]); st.rays++; any = true; }
+                        }
+                    } else
                     for (auto& L : w.l) if (is_idle(L)) {
                         L.live = false;
                         if (cursor < list.size()) { begin(L, rays[list[cursor++]]); st.rays++; any = true; }
@@ -218,6 +232,7 @@ struct Sim {
     void workgroup(const std::vector<Ray>& rays, const std::vector<uint32_t>& list) {
         std::vector<Wave> w(4);
         size_t cursor = 0;
+        pool.clear();
         for (bool any = true; any;) {
             any = false;
             for (auto& x : w) any |= step(x, rays, list, cursor);
@@ -274,6 +289,8 @@ int main(int argc, char** argv) {
         std::string scheme = argv[a];
         const bool postpone = scheme.rfind("pend+", 0) == 0;
         if (postpone) scheme = scheme.substr(5);
+        const int parking = scheme.rfind("park+", 0) == 0 ? 1 : scheme.rfind("wpark+", 0) == 0 ? 2 : 0;
+        if (parking) scheme = scheme.substr(parking == 1 ? 5 : 6);
         int WX = 8, WY = 4, NU = 8, NV = 4, OX = 0, OY = 0; char ord = 'd';
         const bool tile = scheme == "tile";
         if (!tile) {
@@ -281,9 +298,9 @@ int main(int argc, char** argv) {
         }
         if (OX <= 0) OX = WX;
         if (OY <= 0) OY = WY;
-        Stats per_lobe[8];
+        Stats per_lobe[8]; long long parked_tot[8] = {0};
         for (const auto& g : groups) {
-            Sim sim(sc); sim.postpone = postpone;
+            Sim sim(sc); sim.postpone = postpone; sim.parking = parking; if (getenv("WAVESIM_POOL_TAKE")) sim.pool_take = atoi(getenv("WAVESIM_POOL_TAKE"));
             // windows of WX x WY pixels (the host's block-ordered pixel list cuts them; a tile = 8 x 4: half an 8 x 8 block)
             for (int wy = 0; wy + WY <= block; wy += WY)
                 for (int wx = 0; wx + WX <= block; wx += WX) {
@@ -309,6 +326,7 @@ int main(int argc, char** argv) {
             t.rays += s.rays; t.node_visits += s.node_visits; t.tri_tests += s.tri_tests; t.node_iters += s.node_iters; t.shared_iters += s.shared_iters; t.shared_visits += s.shared_visits;
             t.leaf_iters += s.leaf_iters; t.refill_rounds += s.refill_rounds; t.drain_node_iters += s.drain_node_iters; t.drain_visits += s.drain_visits; t.node_lines += s.node_lines;
             t.leaf_lines += s.leaf_lines; t.ge32_iters += s.ge32_iters; t.ge32_visits += s.ge32_visits; t.shared_tests += s.shared_tests;
+            t.shared_tests += 0; parked_tot[g.lobe & 7] += sim.parked;
             t.ns_leaf_lanes += s.ns_leaf_lanes; t.ns_idle_lanes += s.ns_idle_lanes; t.ls_node_lanes += s.ls_node_lanes; t.ls_idle_lanes += s.ls_idle_lanes; t.shared_out_lanes += s.shared_out_lanes;
         }
         for (int l = 0; l < 8; ++l) {
@@ -320,12 +338,12 @@ int main(int argc, char** argv) {
                    "\"node_step_lane_util\": %.4f, \"leaf_step_lane_util\": %.4f, \"shared_visit_share\": %.4f, \"shared_step_share\": %.4f, \"ge32_step_share\": %.4f, \"ge32_visit_share\": %.4f, "
                    "\"node_steps_per_ray\": %.4f, \"leaf_steps_per_ray\": %.4f, \"refill_rounds_per_ray\": %.5f, \"drain_node_step_share\": %.4f, \"drain_lane_util\": %.4f, "
                    "\"node_step_lanes_waiting_at_a_leaf\": %.4f, \"node_step_lanes_idle\": %.4f, \"node_step_lanes_sitting_out_a_shared_step\": %.4f, \"leaf_step_lanes_waiting_at_a_node\": %.4f, \"leaf_step_lanes_idle\": %.4f, "
-                   "\"records_per_regular_node_step\": %.2f, \"records_per_leaf_step\": %.2f, \"vector_loads_per_ray\": %.3f, \"modelled_traversal_vector_instructions_per_ray\": %.2f}\n",
-                   (std::string(postpone ? "pend+" : "") + scheme).c_str(), l, s.rays, (long long)WX * WY * spp, s.node_visits / R, s.tri_tests / R, (double)s.node_visits / (64.0 * s.node_iters), (double)s.tri_tests / (64.0 * s.leaf_iters),
+                   "\"records_per_regular_node_step\": %.2f, \"records_per_leaf_step\": %.2f, \"vector_loads_per_ray\": %.3f, \"modelled_traversal_vector_instructions_per_ray\": %.2f, \"parked_per_ray\": %.4f}\n",
+                   (std::string(postpone ? "pend+" : parking == 1 ? "park+" : parking == 2 ? "wpark+" : "") + scheme).c_str(), l, s.rays, (long long)WX * WY * spp, s.node_visits / R, s.tri_tests / R, (double)s.node_visits / (64.0 * s.node_iters), (double)s.tri_tests / (64.0 * s.leaf_iters),
                    (double)s.shared_visits / s.node_visits, (double)s.shared_iters / s.node_iters, (double)s.ge32_iters / s.node_iters, (double)s.ge32_visits / s.node_visits,
                    s.node_iters / R, s.leaf_iters / R, s.refill_rounds / R, (double)s.drain_node_iters / s.node_iters, s.drain_node_iters ? (double)s.drain_visits / (64.0 * s.drain_node_iters) : 0.0,
                    s.ns_leaf_lanes / (64.0 * s.node_iters), s.ns_idle_lanes / (64.0 * s.node_iters), s.shared_out_lanes / (64.0 * s.node_iters), s.ls_node_lanes / (64.0 * s.leaf_iters), s.ls_idle_lanes / (64.0 * s.leaf_iters),
-                   reg > 0 ? s.node_lines / reg : 0.0, (double)s.leaf_lines / s.leaf_iters, (reg * 4.0 + s.leaf_iters * 3.0) / R, model);
+                   reg > 0 ? s.node_lines / reg : 0.0, (double)s.leaf_lines / s.leaf_iters, (reg * 4.0 + s.leaf_iters * 3.0) / R, model, parked_tot[l] / R);
             fflush(stdout);
         }
     }

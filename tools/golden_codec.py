@@ -72,3 +72,26 @@ def delta_decode(pred, d8, idx, val):
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# tests/golden/pt_single_cfg5_reference.npz: BASELINE configs[4] size (train_emitter's inner loop: 8 192 pixels x spp 32 per call) on the bench scene
+CFG5 = dict(H=1080, W=1920, RAYS=8192, SPP=32, VIEW=0, TRIS=1_000_000, SLF_H=256, SEED=0, SCENE_SEED=1)
+
+
+def cfg5_rays_pick():
+    """the 8 192 pixels of the fixture (and of tests/test_cfg5_full_size.py): torch.randint under a CPU generator seeded 0"""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(0)
+    return torch.randint(0, CFG5["H"] * CFG5["W"], (CFG5["RAYS"],), generator=g)
+
+
+def cfg5_draw(oracle, k, shape):
+    """what the k-th torch.rand(shape) of the replayed path_tracing_single call returned: the first numel values of Philox stream 16 + k"""
+    n = int(np.prod(shape))
+    return np.ascontiguousarray(oracle.philox_u2(CFG5["SEED"], 0, 16 + k, (n + 1) // 2).reshape(-1)[:n].reshape(shape), np.float32)
+
+
+def flipped_pixels(L, L_ref, tol=1e-4):
+    """pixels whose radiance differs from the reference's by more than rounding in some channel: a path of the pixel took another discrete turn"""
+    L = np.asarray(L, np.float64); L_ref = np.asarray(L_ref, np.float64)
+    return (np.abs(L - L_ref) > tol * np.maximum(np.abs(L_ref), 1e-3)).any(-1)
