@@ -562,6 +562,10 @@ def main():
         result["extras"]["cfg5_path_tracing_single_network_evaluated_twice_as_the_reference"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp",
                                                                                                                     skip_unused_material=False, stages=False)
         result["extras"]["cfg5_path_tracing_single_stub_material"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="stub", stages=False)
+        # the step's independent forward calls issued on two HIP streams (the same calls, the same draws: what a training loop on this chip does), and the whole step
+        # captured as a HIP graph and replayed (both: same results as the plain loop, tests/test_pt_single.py)
+        result["extras"]["cfg5_path_tracing_single_calls_on_two_streams"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", stages=False, streams=2)
+        result["extras"]["cfg5_path_tracing_single_hip_graph_replay"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", stages=False, graph=True)
         # ---- refine_shading's diffuse pass (spp 128, 5 bounces, NEE + MIS) through the same network: the reference's batch and this build's default (16 x)
         from tools import bench_refine
         result["extras"]["refine_diffuse_pass_reference_batch"] = bench_refine.run_f1(scene, emitter, slf_np, dev, batch_pixels=10240, batches=4)

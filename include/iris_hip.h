@@ -218,6 +218,15 @@ IRIS_API int iris_pt_brdf_finish(const iris_emitter *, const iris_slf *, const f
  * + cst[i]) with NaN -> 0, then throughput[i] *= weight[i].  rows, throughput, e/coef, cst, weight are each nullable. */
 IRIS_API int iris_pt_apply(float *L, const int32_t *rows, float *throughput, const float *radiance, const int32_t *e, const float *coef,
                   const float *cst, const float *weight, int64_t N, int nan_to_zero, iris_stream_t);
+/* trace_indirect's end of a bounce (utils/path_tracing.py:488-501: `position = position[valid_next]` and its siblings): the rows with keep[i] != 0 are moved to the front
+ * of the output arrays IN ORDER, as boolean indexing does -- n3 arrays of 3 floats per row (bit k of negate3: dst3[k] = -src3[k], the reference's `wo = -wi`), n1 of one
+ * float, ni of one int32 (each at most 6; the pointer arrays are host arrays of device pointers, read during the call); *count (device int32) receives the number of rows
+ * kept.  Outputs must hold N rows and must not alias the inputs.  Two launches on the stream, no host round trip, no index tensors.  workspace: device scratch of
+ * iris_pt_compact_workspace_bytes(N) bytes. */
+IRIS_API uint64_t iris_pt_compact_workspace_bytes(int64_t N);
+IRIS_API int iris_pt_compact(const uint8_t *keep, int64_t N, int n3, const float *const *src3, float *const *dst3, uint32_t negate3,
+                    int n1, const float *const *src1, float *const *dst1, int ni, const int32_t *const *srci, int32_t *const *dsti,
+                    int32_t *count, void *workspace, uint64_t workspace_bytes, iris_stream_t);
 /* :406  L (B,3) = mean over spp; path_of (B*spp) maps a path to its row in the compacted stage arrays (or -1).
  * radiance: the (n_rad,3) parameter tensor itself (model/emitter.py:268). */
 IRIS_API int iris_pt_accumulate_fwd(const float *radiance, const int32_t *e0, const int32_t *path_of, const int32_t *e1, const float *coef1,

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "iris_pt_brdf_finish": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _F, _F, _P],
     "iris_pt_primary": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "iris_pt_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
+    "iris_pt_compact_workspace_bytes": [_I64],
+    "iris_pt_compact": [_P, _I64, _I32, _P, _P, C.c_uint32, _I32, _P, _P, _I32, _P, _P, _P, _P, C.c_uint64, _P],
     "iris_pt_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
     "iris_pt_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],
     "iris_slf_scatter_add": [_P, _P, _P, _I64, _P, _P, _P],
@@ -92,7 +94,7 @@ PROTOTYPES = {
     "iris_version": [],
 }
 _RESTYPE = {"iris_scene_destroy": None, "iris_slf_destroy": None, "iris_emitter_destroy": None,
-            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_debug_source_hash": C.c_char_p, "iris_ngp_n_params": C.c_int64, "iris_ngp_destroy": None, "iris_bake_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
+            "iris_last_error": C.c_char_p, "iris_version": C.c_char_p, "iris_debug_build_flags": C.c_char_p, "iris_debug_source_hash": C.c_char_p, "iris_ngp_n_params": C.c_int64, "iris_ngp_destroy": None, "iris_bake_workspace_bytes": C.c_uint64, "iris_pt_compact_workspace_bytes": C.c_uint64, "iris_denoise_workspace_bytes": C.c_uint64}
 
 _lib = None
 

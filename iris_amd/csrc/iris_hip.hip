@@ -1393,6 +1393,30 @@ extern "C" IRIS_API int iris_pt_apply(float* L, const int32_t* rows, float* thro
     return IRIS_OK;
 }
 
+extern "C" IRIS_API uint64_t iris_pt_compact_workspace_bytes(int64_t N) {
+    return N <= 0 ? 0 : (uint64_t)((N + kCompactItems - 1) / kCompactItems) * sizeof(int32_t);
+}
+extern "C" IRIS_API int iris_pt_compact(const uint8_t* keep, int64_t N, int n3, const float* const* src3, float* const* dst3, uint32_t negate3, int n1,
+                               const float* const* src1, float* const* dst1, int ni, const int32_t* const* srci, int32_t* const* dsti, int32_t* count,
+                               void* workspace, uint64_t workspace_bytes, iris_stream_t stream) {
+    if (N < 0 || !count || n3 < 0 || n1 < 0 || ni < 0 || n3 > kCompactMax || n1 > kCompactMax || ni > kCompactMax || (N > 0 && (!keep || !workspace)) ||
+        (n3 > 0 && (!src3 || !dst3)) || (n1 > 0 && (!src1 || !dst1)) || (ni > 0 && (!srci || !dsti)))
+        return fail(IRIS_ERR_ARG, "iris_pt_compact: bad arguments");
+    if (N >= ((int64_t)1 << 31)) return fail(IRIS_ERR_ARG, "iris_pt_compact: more than 2^31 rows");
+    if (workspace_bytes < iris_pt_compact_workspace_bytes(N)) return fail(IRIS_ERR_ARG, "iris_pt_compact: workspace smaller than iris_pt_compact_workspace_bytes(N)");
+    if (N == 0) { HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream)); return IRIS_OK; }
+    CompactArgs a{};
+    a.keep = keep; a.N = N; a.n3 = n3; a.n1 = n1; a.ni = ni; a.negate3 = negate3; a.block_counts = (int32_t*)workspace; a.count = count;
+    for (int j = 0; j < n3; ++j) { if (!src3[j] || !dst3[j]) return fail(IRIS_ERR_ARG, "iris_pt_compact: null array"); a.src3[j] = src3[j]; a.dst3[j] = dst3[j]; }
+    for (int j = 0; j < n1; ++j) { if (!src1[j] || !dst1[j]) return fail(IRIS_ERR_ARG, "iris_pt_compact: null array"); a.src1[j] = src1[j]; a.dst1[j] = dst1[j]; }
+    for (int j = 0; j < ni; ++j) { if (!srci[j] || !dsti[j]) return fail(IRIS_ERR_ARG, "iris_pt_compact: null array"); a.srci[j] = srci[j]; a.dsti[j] = dsti[j]; }
+    const int blocks = (int)((N + kCompactItems - 1) / kCompactItems);
+    hipLaunchKernelGGL(pt_compact_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pt_compact_move_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 // ======================================================================================================
 // 8(f)-2: G-buffer pooling builders (the stages that produce vslf.npz / emitter.pth)
 // ======================================================================================================

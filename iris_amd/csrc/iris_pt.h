@@ -399,6 +399,67 @@ __global__ void pt_apply_kernel(float* __restrict__ Lacc, const int32_t* __restr
     }
 }
 
+// trace_indirect's end of a bounce (utils/path_tracing.py:488-501: `active_next[...] = valid_next; position = position[valid_next]; ...`): the rows with keep[i] != 0 move to
+// the front of the output arrays IN ORDER (boolean indexing keeps the order; the recorded draws of the parity fixtures are consumed in it).  Two launches, no host
+// round trip, no index tensor: (1) every workgroup counts the kept rows of its kCompactItems consecutive rows; (2) every workgroup sums the counts in front of it,
+// scans its own rows and moves them.  Up to kCompactMax arrays of each kind (3 floats / 1 float / 1 int32 per row); negate3 bit k: dst3[k] = -src3[k] (wo = -wi).
+constexpr int kCompactMax = 6, kCompactPerThread = 8, kCompactItems = 256 * kCompactPerThread;
+struct CompactArgs {
+    const uint8_t* keep; int64_t N;
+    int n3, n1, ni; uint32_t negate3;
+    const float* src3[kCompactMax]; float* dst3[kCompactMax];
+    const float* src1[kCompactMax]; float* dst1[kCompactMax];
+    const int32_t* srci[kCompactMax]; int32_t* dsti[kCompactMax];
+    int32_t* block_counts; int32_t* count;
+};
+__global__ __launch_bounds__(256) void pt_compact_count_kernel(CompactArgs a) {
+    __shared__ int s_w[4];
+    const int64_t i0 = (int64_t)blockIdx.x * kCompactItems + (int64_t)threadIdx.x * kCompactPerThread;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactPerThread; ++k) c += (i0 + k < a.N && a.keep[i0 + k]) ? 1 : 0;
+    for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void pt_compact_move_kernel(CompactArgs a) {
+    __shared__ int s_w[4], s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // rows kept by the workgroups in front of this one
+    int before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += a.block_counts[b];
+    for (int m = 1; m < 64; m <<= 1) before += __shfl_xor(before, m);
+    if (lane == 0) s_w[wave] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    // this workgroup's rows: thread t owns kCompactPerThread consecutive rows
+    const int64_t i0 = (int64_t)blockIdx.x * kCompactItems + (int64_t)threadIdx.x * kCompactPerThread;
+    uint32_t mask = 0; int c = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactPerThread; ++k) if (i0 + k < a.N && a.keep[i0 + k]) { mask |= 1u << k; ++c; }
+    int inc = c;
+    for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(inc, m); if (lane >= m) inc += v; }
+    __syncthreads();
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int off = s_base + inc - c;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *a.count = off + c;
+    for (int k = 0; k < kCompactPerThread; ++k) {
+        if (!((mask >> k) & 1u)) continue;
+        const int64_t i = i0 + k, o = off++;
+        for (int j = 0; j < a.n3; ++j) {
+            f3 v = ld3(a.src3[j] + i * 3);
+            if ((a.negate3 >> j) & 1u) v = mk3(-v.x, -v.y, -v.z);
+            st3(a.dst3[j] + o * 3, v);
+        }
+        for (int j = 0; j < a.n1; ++j) a.dst1[j][o] = a.src1[j][i];
+        for (int j = 0; j < a.ni; ++j) a.dsti[j][o] = a.srci[j][i];
+    }
+}
+
 // unfused call-surface kernels
 __global__ void sample_emitter_kernel(EmitSampleDev e, const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ pos,
                                       int64_t N, float* __restrict__ wi, float* __restrict__ pdf, int64_t* __restrict__ tri) {

@@ -170,9 +170,12 @@ _SIDE = {}
 
 
 def _side_stream(dev):
-    """one extra HIP stream per device for stages that are independent of each other"""
-    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    """one extra HIP stream per (device, calling stream) for stages that are independent of each other: calls issued on different streams (a training loop that runs
+    its independent path_tracing_single calls side by side) do not queue their emitter-sampling stages behind one another"""
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     if key not in _SIDE:
+        if len(_SIDE) >= 16:
+            _SIDE.pop(next(iter(_SIDE)))
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
 
@@ -341,10 +344,19 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         L.mark("finish")
         main.wait_event(join)              # (before anything frees or reads the tensors the side stream works on)
         if full and indir_depth > 0:
-            keep = torch.nonzero(hit_valid, as_tuple=False).reshape(-1)
-            L_indir = trace_indirect(scene, emitter_net, material_net, pos_n[keep].contiguous(), (-wi_b[keep]).contiguous(), nrm_n[keep].contiguous(), indir_depth,
-                                     uniforms=u)                                  # (u: what is left of the recorded draws, or None)
-            const2[keep] = const2[keep] + w_b[keep] * L_indir                     # rides on the constant term: no gradient, as in the reference
+            # the paths whose sampled hit neither ended them nor left the scene go on (:300-316): moved to the front on the device, with the material rows just
+            # evaluated at their hits when there are any (trace_indirect's depth 0 would ask the network for them again, :432-433)
+            iota = torch.arange(N, device=dev, dtype=torch.int32)
+            if rough_n is not None:
+                ma, mr, mm = _mat_tensors(mat_next)
+                _, (p_k, n_k, w_k, a_k, wo_k), (r_k, m_k), (keep,) = compact_rows(hit_valid, rows3=(pos_n, nrm_n, w_b, ma), neg3=(wi_b,), rows1=(mr, mm), rowsi=(iota,))
+                mat0 = (a_k, r_k, m_k)
+            else:
+                _, (p_k, n_k, w_k, wo_k), _, (keep,) = compact_rows(hit_valid, rows3=(pos_n, nrm_n, w_b), neg3=(wi_b,), rowsi=(iota,))
+                mat0 = None
+            L_indir = trace_indirect(scene, emitter_net, material_net, p_k, wo_k, n_k, indir_depth, uniforms=u, mat0=mat0)      # (u: what is left of the recorded draws, or None)
+            keep = keep.long()
+            const2[keep] = const2[keep] + w_k * L_indir                           # rides on the constant term: no gradient, as in the reference
     out = _PtAccumulate.apply(radiance, e0, path_of, e1, coef1, e2, coef2, const2, B, spp)
     L.mark("accumulate")
     return out
@@ -380,11 +392,66 @@ def _lobe_trace(scene, position, normal, wo, mat, s1, s2, lobe, roughness=0.0):
     return wi, pdf, w, pos_n, nrm_n, tri_n
 
 
+class _Counts:
+    """Pinned host words the device-side path counts are copied into (one per device): the ONE thing a bounce hands back to the host -- the number of paths that
+    continue, which sizes the next bounce's launches and the material network's evaluation (a caller-supplied callable) -- as a 4-byte copy and an event wait
+    instead of torch.nonzero (a scan, a host synchronisation and an index tensor) plus one ATen gather per state array."""
+    _host = {}
+
+    @classmethod
+    def read(cls, count, dev):
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        h = cls._host.get(key)
+        if h is None:
+            h = cls._host[key] = torch.empty(1, dtype=torch.int32).pin_memory()
+        h.copy_(count, non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev)); ev.synchronize()
+        return int(h[0])
+
+
+def compact_rows(keep, rows3=(), neg3=(), rows1=(), rowsi=()):
+    """Boolean indexing of several per-path arrays by one mask, as ONE order-preserving device-side pass (`iris_pt_compact`): returns (count, [a[keep] for a in rows3] +
+    [-a[keep] for a in neg3], [a[keep] for a in rows1], [a[keep] for a in rowsi]) -- the outputs are views of N-row buffers cut to the count (one 4-byte read-back)."""
+    import ctypes as C
+    keep = L.require_gpu(keep, torch.bool, "keep").reshape(-1)
+    N, dev = keep.shape[0], keep.device
+    in3 = [L.require_gpu(t, torch.float32, "rows3").reshape(N, 3) for t in list(rows3) + list(neg3)]
+    in1 = [L.require_gpu(t, torch.float32, "rows1").reshape(N) for t in rows1]
+    ini = [L.require_gpu(t, torch.int32, "rowsi").reshape(N) for t in rowsi]
+    if max(len(in3), len(in1), len(ini)) > 6:
+        raise L.IrisError("compact_rows: at most 6 arrays of each kind")
+    out3 = [torch.empty(N, 3, device=dev) for _ in in3]; out1 = [torch.empty(N, device=dev) for _ in in1]; outi = [torch.empty(N, device=dev, dtype=torch.int32) for _ in ini]
+    count = torch.empty(1, device=dev, dtype=torch.int32)
+    ws_bytes = int(L.lib().iris_pt_compact_workspace_bytes(N))
+    ws = torch.empty(max(ws_bytes, 4), device=dev, dtype=torch.uint8)
+    arr = lambda ts: (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])          # noqa: E731
+    neg = sum(1 << (len(rows3) + k) for k in range(len(neg3)))
+    with torch.cuda.device(dev):
+        L.check(L.lib().iris_pt_compact(L.ptr(keep), N, len(in3), arr(in3), arr(out3), neg, len(in1), arr(in1), arr(out1), len(ini), arr(ini), arr(outi),
+                                        L.ptr(count), L.ptr(ws), ws_bytes, L.stream()))
+        n = _Counts.read(count, dev)
+    return n, [t[:n] for t in out3], [t[:n] for t in out1], [t[:n] for t in outi]
+
+
+def _bounce_draws(nxt, own, N, dev):
+    """the four draws of a bounce (rand(N), rand(N,2), rand(N), rand(N,2)): recorded ones in the reference's order, or ONE generator launch cut into four
+    (every piece starts at a multiple of four floats)"""
+    if not own:
+        return nxt(N), nxt(N, 2), nxt(N), nxt(N, 2)
+    r4 = lambda n: (n + 3) // 4 * 4          # noqa: E731
+    o1, o2, o3 = r4(N), r4(N) + r4(2 * N), 2 * r4(N) + r4(2 * N)
+    pool = torch.rand(o3 + 2 * N, device=dev)
+    return pool[:N], pool[o1:o1 + 2 * N].reshape(N, 2), pool[o2:o2 + N], pool[o3:o3 + 2 * N].reshape(N, 2)
+
+
 @torch.no_grad()
-def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir_depth, uniforms=None):
+def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir_depth, uniforms=None, mat0=None):
     """indirect illumination: up to indir_depth bounces of emitter sampling + BRDF sampling with power-2 MIS, paths ending at
     emitters / the diffuse radiance cache (utils/path_tracing.py:409-502).  Returns L Bx3.  uniforms: optional list of the
-    draws in the reference's order, per bounce rand(N), rand(N,2), rand(N), rand(N,2)."""
+    draws in the reference's order, per bounce rand(N), rand(N,2), rand(N), rand(N,2).
+    mat0: optional (albedo (B,3), roughness (B), metallic (B)) of `position` when the caller has just evaluated the material network there (the integrators below
+    have, for eval_emitter's roughness test): the reference evaluates it again at depth 0 (:432-433), a deterministic network returns the same rows.
+    Between two bounces the surviving paths are moved to the front of fresh arrays on the device (`compact_rows`); after the last bounce nothing is moved."""
     position = L.require_gpu(position, torch.float32, "position").reshape(-1, 3)
     wo = L.require_gpu(wo, torch.float32, "wo").reshape(-1, 3)
     normal = L.require_gpu(normal, torch.float32, "normal").reshape(-1, 3)
@@ -394,22 +461,21 @@ def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir
     rows = torch.arange(B, device=dev, dtype=torch.int32)
     throughput = torch.ones(B, 3, device=dev)
     radiance = emitter_net.radiance_on(dev)
-    mat = None
+    mat = None if mat0 is None else tuple(L.require_gpu(t, torch.float32, "mat0").reshape(*sh) for t, sh in zip(mat0, ((B, 3), (B,), (B,))))
     with torch.cuda.device(dev):
         eh, sh = emitter_net.handle(dev), emitter_net.slf.handle(dev)
         for depth in range(indir_depth):
             N = position.shape[0]
             if N == 0:
                 break
-            if depth == 0:
+            if depth == 0 and mat is None:
                 mat = _mat_tensors(material_net(position))
             a, r, m = mat
-            s1, s2 = nxt(N), nxt(N, 2)
+            s1, s2, s1b, s2b = _bounce_draws(nxt, uniforms is None, N, dev)
             coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
             L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(a), L.ptr(r), L.ptr(m), L.ptr(s1), L.ptr(s2), N,
                                     L.ptr(coef1), L.ptr(e1), 1e-12, 1e-12, 0.0, L.stream()))
             L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e1), L.ptr(coef1), None, None, N, 1, L.stream()))
-            s1b, s2b = nxt(N), nxt(N, 2)
             wi, pdf, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, mat, s1b, s2b, 0)
             mat_next = _mat_tensors(material_net(pos_n))
             coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
@@ -417,15 +483,17 @@ def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir
             L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi), L.ptr(tri_n), L.ptr(mat_next[1]), L.ptr(pdf), L.ptr(w), N,
                                             L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(valid_next), 0.6, 1e-12, L.stream()))
             L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e2), L.ptr(coef2), L.ptr(const2), L.ptr(w), N, 1, L.stream()))
-            keep = torch.nonzero(valid_next, as_tuple=False).reshape(-1)        # continue only the paths that neither ended nor left the scene
-            rows, throughput = rows[keep].contiguous(), throughput[keep].contiguous()
-            position, wo, normal = pos_n[keep].contiguous(), (-wi[keep]).contiguous(), nrm_n[keep].contiguous()
-            mat = tuple(t[keep].contiguous() for t in mat_next)
+            if depth + 1 == indir_depth:
+                break                                                       # (the reference masks its arrays once more, :488-501, and returns)
+            # continue only the paths that neither ended nor left the scene: position = position_next[valid_next], wo = -wi[valid_next], ... (:488-501)
+            _, (position, normal, throughput, alb, wo), (rgh, mtl), (rows,) = compact_rows(valid_next, rows3=(pos_n, nrm_n, throughput, mat_next[0]), neg3=(wi,),
+                                                                                          rows1=(mat_next[1], mat_next[2]), rowsi=(rows,))
+            mat = (alb, rgh, mtl)
     return Lacc
 
 
 @torch.no_grad()
-def _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, lobe, roughness, uniforms):
+def _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, lobe, roughness, uniforms, reuse_material=True):
     positions = L.require_gpu(positions, torch.float32, "positions").reshape(-1, 3)
     wis = L.require_gpu(wis, torch.float32, "wis").reshape(-1, 3)
     normals = L.require_gpu(normals, torch.float32, "normals").reshape(-1, 3)
@@ -445,28 +513,34 @@ def _det_common(scene, emitter_net, material_net, positions, wis, normals, trian
         wi, _, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, None, None, s2, lobe, roughness)
         mat_next = material_net(pos_n)
         Le, _, valid_next = emitter_net.eval_emitter(pos_n, wi, tri_n, mat_next["roughness"])        # default trace_roughness = 0.6
-        keep = torch.nonzero(valid_next, as_tuple=False).reshape(-1)
-        L_indir = trace_indirect(scene, emitter_net, material_net, pos_n[keep], -wi[keep], nrm_n[keep], indir_depth, uniforms=u)
+        # the paths that go on (:96-104 / :176-184): their state -- and the material rows just evaluated at their hits, which trace_indirect's depth 0 would ask the
+        # network for a second time (:432-433) -- moved to the front on the device
+        ma, mr, mm = _mat_tensors(mat_next)
+        iota = torch.arange(N, device=dev, dtype=torch.int32)
+        _, (p_k, n_k, a_k, wo_k), (r_k, m_k), (keep,) = compact_rows(valid_next, rows3=(pos_n, nrm_n, ma), neg3=(wi,), rows1=(mr, mm), rowsi=(iota,))
+        L_indir = trace_indirect(scene, emitter_net, material_net, p_k, wo_k, n_k, indir_depth, uniforms=u, mat0=(a_k, r_k, m_k) if reuse_material else None)
         total = Le.clone()
-        total[keep] += L_indir                 # both weights multiply (Le + L_indir) of the same path
+        total[keep.long()] += L_indir          # both weights multiply (Le + L_indir) of the same path
     return sel, w, total.reshape(P, spp, 3)
 
 
-def path_tracing_det_diff(scene, emitter_net, material_net, positions, wis, normals, uvs, triangle_idxs, spp, indir_depth, uniforms=None):
+def path_tracing_det_diff(scene, emitter_net, material_net, positions, wis, normals, uvs, triangle_idxs, spp, indir_depth, uniforms=None, reuse_material=True):
     """diffuse shading with a deterministic first intersection and indir_depth bounces of indirect light
-    (utils/path_tracing.py:50-124).  Returns Lout Bx3 (zeros where triangle_idxs == -1)."""
+    (utils/path_tracing.py:50-124).  Returns Lout Bx3 (zeros where triangle_idxs == -1).
+    reuse_material: the material rows evaluated at the sampled hits (for eval_emitter's roughness test, :90) are handed to trace_indirect, whose depth 0 would evaluate
+    the network at the same points again (:432-433) -- the same rows for a deterministic network, one evaluation of ~six per path less; False = evaluate twice, as written."""
     Lout = torch.zeros_like(positions.reshape(-1, 3))
-    sel, w, total = _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, 1, 0.0, uniforms)
+    sel, w, total = _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, 1, 0.0, uniforms, reuse_material)
     if total is not None:
         Lout[sel] = total.mean(1)              # sample_diffuse's brdf_weight is 1 (model/brdf.py:86)
     return Lout
 
 
-def path_tracing_det_spec(scene, emitter_net, material_net, roughness_level, positions, wis, normals, uvs, triangle_idxs, spp, indir_depth, uniforms=None):
+def path_tracing_det_spec(scene, emitter_net, material_net, roughness_level, positions, wis, normals, uvs, triangle_idxs, spp, indir_depth, uniforms=None, reuse_material=True):
     """the two Fresnel-split specular shadings at one roughness level (utils/path_tracing.py:126-212).  Returns L0out, L1out."""
     L0 = torch.zeros_like(positions.reshape(-1, 3)); L1 = torch.zeros_like(L0)
     r = float(roughness_level.detach().float().cpu().item()) if isinstance(roughness_level, torch.Tensor) else float(roughness_level)
-    sel, w, total = _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, 2, r, uniforms)
+    sel, w, total = _det_common(scene, emitter_net, material_net, positions, wis, normals, triangle_idxs, spp, indir_depth, 2, r, uniforms, reuse_material)
     if total is not None:
         P, spp_ = total.shape[0], total.shape[1]
         g = w.reshape(P, spp_, 3)

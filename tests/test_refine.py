@@ -62,3 +62,59 @@ def test_hip_refine(tmp_path, oracle_mod):
     torch.manual_seed(0)
     L2 = path_tracing_det_diff(sc, em, mat, T(r["position"]), T(r["rays_d"]), T(r["normal"]), None, T(r["triangle_idx"]), 8, 5)
     assert torch.isfinite(L2).all() and float(L2.min()) >= 0.0
+
+
+@pytest.mark.gpu
+def test_compact_rows_is_boolean_indexing():
+    """iris_pt_compact (trace_indirect's `x = x[valid_next]`, utils/path_tracing.py:488-501) against torch's boolean indexing: same rows, same ORDER, several arrays of each kind,
+    sizes around the 2048-row workgroup granularity, all / none kept, the negated array."""
+    from iris_amd.utils.path_tracing import compact_rows
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for N in (0, 1, 7, 2047, 2048, 2049, 4096 * 3 + 5, 1_000_003):
+        for frac in (0.0, 0.37, 1.0):
+            keep = (torch.rand(N, generator=g) < frac).to(dev) if 0.0 < frac < 1.0 else torch.full((N,), frac == 1.0, dtype=torch.bool, device=dev)
+            a3 = [torch.randn(N, 3, generator=g).to(dev) for _ in range(4)]
+            n3 = torch.randn(N, 3, generator=g).to(dev)
+            a1 = [torch.randn(N, generator=g).to(dev) for _ in range(2)]
+            ai = [torch.randint(-5, 1 << 30, (N,), generator=g, dtype=torch.int32).to(dev)]
+            n, o3, o1, oi = compact_rows(keep, rows3=a3, neg3=(n3,), rows1=a1, rowsi=ai)
+            assert n == int(keep.sum())
+            for got, src in zip(o3, a3 + [-n3]):
+                assert got.shape == (n, 3) and torch.equal(got, src[keep])
+            for got, src in zip(o1, a1):
+                assert torch.equal(got, src[keep])
+            assert torch.equal(oi[0], ai[0][keep])
+
+
+@pytest.mark.gpu
+def test_material_rows_handed_to_trace_indirect_change_nothing(tmp_path):
+    """path_tracing_det_diff / _spec evaluate the material network at the sampled hits (for eval_emitter's roughness test) and the reference's trace_indirect evaluates it AGAIN
+    at the same points at depth 0 (utils/path_tracing.py:432-433).  Handing the rows over (reuse_material, the default) must give the bits of evaluating twice -- with recorded
+    draws and with the integrator's own -- and the network must be asked for fewer points."""
+    from iris_amd.utils.path_tracing import path_tracing_det_diff, path_tracing_det_spec
+    dev = torch.device("cuda:0")
+    _, _, sc, em = _gpu_setup(tmp_path, dev)
+    r = golden("refine.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    class Counting(StubMaterial):
+        points = 0
+
+        def forward(self, x):
+            Counting.points += int(x.shape[0])
+            return super().forward(x)
+    mat = Counting()
+    args = (T(r["position"]), T(r["rays_d"]), T(r["normal"]), None, T(r["triangle_idx"]), SPP, DEPTH)
+    out = {}
+    for reuse in (True, False):
+        Counting.points = 0
+        Ld = path_tracing_det_diff(sc, em, mat, *args, uniforms=[T(x) for x in _u(r, "d")], reuse_material=reuse)
+        L0, L1 = path_tracing_det_spec(sc, em, mat, torch.tensor(0.412), *args, uniforms=[T(x) for x in _u(r, "s")], reuse_material=reuse)
+        torch.manual_seed(11)
+        Lf = path_tracing_det_diff(sc, em, mat, T(r["position"]), T(r["rays_d"]), T(r["normal"]), None, T(r["triangle_idx"]), 16, 5, reuse_material=reuse)
+        out[reuse] = (Ld, L0, L1, Lf, Counting.points)
+    for a, b in zip(out[True][:4], out[False][:4]):
+        assert torch.equal(a, b)
+    assert out[True][4] < out[False][4]
+    assert rel_l2(out[True][0].cpu().numpy(), r["L_det_diff"]) <= 1e-4

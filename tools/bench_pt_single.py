@@ -33,7 +33,7 @@ L2_PEAK_GBPS = 34500.0        # aggregate L2 bandwidth of the 8 XCDs (MI355X_MIC
 
 
 def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp=32, calls=4, graph=False, material="ngp", skip_unused_material=True, stages=True,
-        bake_mrays_per_s=None):
+        bake_mrays_per_s=None, streams=1):
     """-> dict: Mpaths/s of `steps` training steps (each `calls` forward calls + one backward) on an existing bench workload.
     material: "ngp" = NGPBRDF with random parameters (the reference's network), "stub" = the closed-form stand-in of rounds 1-3
     skip_unused_material: path_tracing_single's default (True): the network's second evaluation per call, whose only use is a test its roughness bound decides,
@@ -61,12 +61,31 @@ def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp
     mat = ngp_material(slf, dev) if material == "ngp" else GpuStub()
     target = torch.rand(rays, 3, device=dev)
 
+    pool = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else []
+
     def step():
         em.radiance.grad = None
         loss = 0
-        for _ in range(calls):
-            L = path_tracing_single(scene, em, mat, o, d, dx, dy, spp, skip_unused_material=skip_unused_material)
-            loss = loss + ((L - target) ** 2).mean()
+        if pool:
+            # the `calls` forward passes of a step are independent of each other (the same rays, fresh draws: train_emitter.py:181-189 runs them one after the other only
+            # because it is a Python loop): issued round-robin on `streams` HIP streams, the latency-bound stages of one call run beside those of the next
+            main = torch.cuda.current_stream(dev)
+            ev = torch.cuda.Event(); ev.record(main)
+            Ls = []
+            for c in range(calls):
+                st = pool[c % streams]
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    Ls.append(path_tracing_single(scene, em, mat, o, d, dx, dy, spp, skip_unused_material=skip_unused_material))
+            for st in pool:
+                main.wait_stream(st)
+            for L in Ls:
+                L.record_stream(main)
+                loss = loss + ((L - target) ** 2).mean()
+        else:
+            for _ in range(calls):
+                L = path_tracing_single(scene, em, mat, o, d, dx, dy, spp, skip_unused_material=skip_unused_material)
+                loss = loss + ((L - target) ** 2).mean()
         loss.backward()
         return loss
     for _ in range(warmup):
@@ -137,7 +156,7 @@ def run(room, slf, emi, scene, emitter0, dev, steps=10, warmup=2, rays=8192, spp
                                                "issue), which is why one call of spp = SPP (4 x the rays) runs at twice the path rate"}
     return {"metric": "path_tracing_single fwd+bwd (BASELINE configs[4]: train_emitter.py:181-189)", "value": round(paths / dt / 1e6, 2), "unit": "Mpaths/s",
             "ms_per_step": round(dt / steps * 1e3, 2),
-            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "hip_graph": bool(graph), "triangles": int(room["faces"].shape[0]), "material": ("NGPBRDF (hash grid 32 x 2 x 2^19 + MLP 64 x 2 on the matrix cores), random parameters" if material == "ngp" else "closed-form stub")},
+            "config": {"rays": rays, "spp": spp, "calls_per_step": calls, "hip_graph": bool(graph), "streams": int(streams), "triangles": int(room["faces"].shape[0]), "material": ("NGPBRDF (hash grid 32 x 2 x 2^19 + MLP 64 x 2 on the matrix cores), random parameters" if material == "ngp" else "closed-form stub")},
             "skip_unused_material": bool(skip_unused_material and material == "ngp"), "stages": stage_info,
             "grad_nonzero_rows": int((em.radiance.grad.abs().sum(-1) > 0).sum())}
 
@@ -147,6 +166,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rays", type=int, default=8192); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--calls", type=int, default=4)
     ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--streams", type=int, default=1, help="issue the independent forward calls of a step round-robin on this many HIP streams")
     ap.add_argument("--graph", action="store_true", help="capture the training step in a HIP graph (torch.cuda.CUDAGraph) and replay it")
     ap.add_argument("--material", choices=["ngp", "stub"], default="ngp")
     ap.add_argument("--no-skip", action="store_true", help="evaluate the material network at the sampled hits as the reference does (path_tracing_single skip_unused_material=False)")
@@ -162,7 +182,7 @@ def main():
         L.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
     ns = argparse.Namespace(scene_seed=1, tris=args.tris, slf_res=256, layout=0)
     room, slf, emi, scene, emitter0 = bench.build_workload(ns, dev)
-    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph, material=args.material, skip_unused_material=not args.no_skip)))
+    print(json.dumps(run(room, slf, emi, scene, emitter0, dev, args.steps, args.warmup, args.rays, args.spp, args.calls, graph=args.graph, material=args.material, skip_unused_material=not args.no_skip, streams=args.streams)))
 
 
 if __name__ == "__main__":
