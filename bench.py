@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "pmc_r5.json"
+PMC_FILES = ["pmc_r6.json", "pmc_r6_world2.json", "pmc_r6_world4.json", "pmc_r6_world8.json"]     # N = 1, and rank 0's stripes of an N-rank run (EMULATED on one GPU: bench.py --emulate-world N)
 N_SIMD, N_CU = 1024, 256
 
 
@@ -97,21 +97,27 @@ def spawn_workers(n):
 
 
 def load_pmc(rays_per_launch, node_bytes):
-    """Per-launch counters of the timed kernel from the committed rocprofv3 passes (profiles/pmc_r3.json; PMC counters cannot be read from
-    inside this process).  Refused -- reported as stale -- unless they were taken on exactly the kernel sources this library was built
-    from and on the same launch size."""
+    """Per-launch counters of the timed kernel from the committed rocprofv3 passes (PMC counters cannot be read from inside this process): the profile among
+    PMC_FILES that was taken on exactly the kernel sources this library was built from AND on this launch size -- the whole view at N = 1, rank 0's stripes of an
+    N-rank run otherwise (those passes are taken with --emulate-world N on one GPU and say so).  None + the reason when there is no such profile."""
     from iris_amd import _lib as L
-    path = os.path.join(REPO, "profiles", PMC_FILE)
-    try:
-        pj = json.load(open(path))
-    except Exception as e:     # noqa
-        return None, f"profiles/{PMC_FILE} unreadable ({e})"
     have = L.source_hash()
-    if pj.get("source_hash") != have:
-        return None, f"stale: profile taken on kernel sources {pj.get('source_hash')}, this build is {have}"
-    if abs(pj.get("rays_per_launch", 0) - rays_per_launch) > 0.01 * rays_per_launch or node_bytes != 64:
-        return None, f"profile is for {pj.get('rays_per_launch')} rays per launch, this run launches {rays_per_launch:.0f}"
-    return pj, "committed"
+    why = []
+    for name in PMC_FILES:
+        try:
+            pj = json.load(open(os.path.join(REPO, "profiles", name)))
+        except Exception as e:     # noqa
+            why.append(f"profiles/{name} unreadable ({type(e).__name__})")
+            continue
+        if pj.get("source_hash") != have:
+            why.append(f"profiles/{name}: stale (taken on kernel sources {pj.get('source_hash')}, this build is {have})")
+            continue
+        if abs(pj.get("rays_per_launch", 0) - rays_per_launch) > 0.01 * rays_per_launch or node_bytes != 64:
+            why.append(f"profiles/{name}: {pj.get('rays_per_launch')} rays per launch, this run launches {rays_per_launch:.0f}")
+            continue
+        pj["_file"] = name
+        return pj, "committed (profiles/" + name + (", taken with --emulate-world %d on one GPU" % pj["emulated_world"] if pj.get("emulated_world") else "") + ")"
+    return None, "; ".join(why)
 
 
 def main():
@@ -346,6 +352,8 @@ def main():
                                                                                                                         f"{world} x interleaved {sh.STRIPE_ROWS}-row stripes, 1 {args.gather} per view"),
                    "bvh": {"layout": info["layout"], "nodes": info["n_nodes"], "node_bytes": info["node_bytes"], "tri_bytes": info["tri_bytes"], "depth": info["depth"],
                            "sah_cost": round(info["sah_cost"], 3), "build_seconds": round(info["build_seconds"], 2)}},
+        "emulated": ({"world": args.emulate_world, "rank": args.emulate_rank % args.emulate_world, "note": "ONE rank's stripes of an N-rank run baked on one GPU, no collective: `value` is NOT the headline metric"}
+                     if (args.emulate_world > 1 and world == 1) else None),
         "multi_gpu": {"backend": (("rccl" if backend == "nccl" else backend) if have_pg else None), "process_group": have_pg, "forced_at_world_1": bool(force_pg and world == 1),
                       "ranks_seen_by_all_reduce": int(ranks_seen.item()) if have_pg else None, "per_rank_ms_per_step": [round(x / max(args.steps, 1) * 1e3, 3) for x in per_rank],
                       "gather_ms": round(float(np.mean([a.elapsed_time(b) for a, b in ev_gather])), 3) if ev_gather else None,
@@ -427,7 +435,7 @@ def main():
             valu_prof = quads_per_ray * prof_rate / 1e9
             # `frac` of every roof FOLLOWS THIS RUN (advisor round 4): the profiled per-ray counters x THIS run's ray rate inside the kernel (HIP events), against the
             # hardware peak at the 2.4 GHz peak shader clock (a roof is a hardware peak; the clock a box sustains under this kernel is 2.25 ... 2.36 GHz).
-            # `frac_profiled` = counters and duration of the SAME profiled launches at THEIR clock: a constant of profiles/PMC_FILE, kept for recomputation.
+            # `frac_profiled` = counters and duration of the SAME profiled launches at THEIR clock: a constant of the profile, kept for recomputation.
             peak_clock = 2.4e9
             valu_peak_hw = N_SIMD * peak_clock / 4 / 1e9
             ta_peak_hw = N_CU * peak_clock / 1e9
@@ -437,7 +445,7 @@ def main():
                          "frac_with_this_runs_ray_rate_at_the_profiled_clock": round(valu_ach / valu_peak, 4),
                          "useful_lane_frac": round(valu_ach / valu_peak_hw * lane_util, 4),
                          "frac_note": "frac = profiled issue quad-cycles per ray x THIS run's in-kernel ray rate (HIP events) / the roof at the 2.4 GHz peak clock: it moves with the run.  frac_profiled = counters and duration of the "
-                                      "SAME profiled launches at THEIR clock (GRBM_GUI_ACTIVE / duration: the chip lowers its clock under this kernel, differently from box to box; a constant of profiles/" + PMC_FILE + "); "
+                                      "SAME profiled launches at THEIR clock (GRBM_GUI_ACTIVE / duration: the chip lowers its clock under this kernel, differently from box to box; a constant of the profile); "
                                       "frac_profiled_at_2400_MHz = the same against the peak-clock roof; useful_lane_frac = frac x SIMD lane utilisation: the share of the VALU "
                                       "LANE-cycles that did work; pure instruction streams top out at 0.88 (v_fma_f32, dual issue) ... 0.94-0.97 (4- and 8-cycle classes): profiles/r3_counter_calibration.json",
                          "wave_instructions_per_ray": round(valu_inst_per_ray, 1), "issue_quads_per_ray": round(quads_per_ray, 1),
@@ -455,7 +463,7 @@ def main():
             bound = max(roofs, key=lambda k: roofs[k]["frac"])
         rl = {"kernel": "bake_view_kernel<Q8> (all lobes of a view, one persistent launch)", "launch_ms": round(avg_ms, 3), "launches": len(ms),
               "rays_per_launch": int(rays_per_launch), "mrays_per_s_kernel": round(rate / 1e6, 1), "pmc_source": src,
-              "pmc_file": "profiles/" + PMC_FILE if pj else None, "roofs": roofs, "traffic": traffic,
+              "pmc_file": "profiles/" + pj["_file"] if pj else None, "roofs": roofs, "traffic": traffic,
               "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "algorithmic_GBps_cache_served_exceeds_hbm_peak": round(bytes_per_ray * rate / 1e9, 1),
               "algorithmic_note": "SURVEY 8(d) byte model; these bytes are served by L1 / L2 / Infinity Cache, so the figure exceeds the HBM peak and is not a roof",
               "work_per_ray": work}
@@ -562,16 +570,20 @@ def main():
         result["extras"]["cfg5_path_tracing_single_network_evaluated_twice_as_the_reference"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp",
                                                                                                                     skip_unused_material=False, stages=False)
         result["extras"]["cfg5_path_tracing_single_stub_material"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="stub", stages=False)
-        # the step's independent forward calls issued on two HIP streams (the same calls, the same draws: what a training loop on this chip does), and the whole step
-        # captured as a HIP graph and replayed (both: same results as the plain loop, tests/test_pt_single.py)
-        result["extras"]["cfg5_path_tracing_single_calls_on_two_streams"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", stages=False, streams=2)
+        # A/B rows of the same step (same results as the plain loop, tests/test_pt_single.py): its four independent forward calls issued round-robin on four HIP streams
+        # (what a training loop on this chip does: the stages of a 262 144-path call are latency-bound, one call's run beside the next's); the whole step captured as a
+        # HIP graph and replayed; and the step as ONE call of spp = SPP = 128 (train_emitter.py:181-189 splits it into SPP // spp calls on the same rays to bound ITS memory:
+        # the same estimator, a launch that fills the chip)
+        result["extras"]["cfg5_path_tracing_single_calls_on_four_streams"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", stages=False, streams=4)
         result["extras"]["cfg5_path_tracing_single_hip_graph_replay"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", stages=False, graph=True)
+        result["extras"]["cfg5_path_tracing_single_one_call_of_spp_128"] = bench_pt_single.run(room, slf_np, emi_np, scene, emitter, dev, steps=20, warmup=3, material="ngp", stages=False, spp=128, calls=1)
         # ---- refine_shading's diffuse pass (spp 128, 5 bounces, NEE + MIS) through the same network: the reference's batch and this build's default (16 x)
         from tools import bench_refine
         result["extras"]["refine_diffuse_pass_reference_batch"] = bench_refine.run_f1(scene, emitter, slf_np, dev, batch_pixels=10240, batches=4)
         result["extras"]["refine_diffuse_pass_default_batch"] = bench_refine.run_f1(scene, emitter, slf_np, dev, batch_pixels=163840, batches=2)
 
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0:
+        # (at N > 1 too: the timed region is over -- `value` is final --, the other ranks wait in the closing barrier, whose timeout is --collective-timeout)
         # ---- CPU baseline: the oracle (port of the same algorithm) on a bounded pixel sample of the same workload ----
         import oracle
         oracle.build()

@@ -403,7 +403,7 @@ __global__ void pt_apply_kernel(float* __restrict__ Lacc, const int32_t* __restr
 // the front of the output arrays IN ORDER (boolean indexing keeps the order; the recorded draws of the parity fixtures are consumed in it).  Two launches, no host
 // round trip, no index tensor: (1) every workgroup counts the kept rows of its kCompactItems consecutive rows; (2) every workgroup sums the counts in front of it,
 // scans its own rows and moves them.  Up to kCompactMax arrays of each kind (3 floats / 1 float / 1 int32 per row); negate3 bit k: dst3[k] = -src3[k] (wo = -wi).
-constexpr int kCompactMax = 6, kCompactPerThread = 8, kCompactItems = 256 * kCompactPerThread;
+constexpr int kCompactMax = 6, kCompactRounds = 8, kCompactItems = 256 * kCompactRounds;   // rows per workgroup: every wave takes 8 runs of 64 CONSECUTIVE rows (lane = row: coalesced)
 struct CompactArgs {
     const uint8_t* keep; int64_t N;
     int n3, n1, ni; uint32_t negate3;
@@ -412,51 +412,53 @@ struct CompactArgs {
     const int32_t* srci[kCompactMax]; int32_t* dsti[kCompactMax];
     int32_t* block_counts; int32_t* count;
 };
-__global__ __launch_bounds__(256) void pt_compact_count_kernel(CompactArgs a) {
-    __shared__ int s_w[4];
-    const int64_t i0 = (int64_t)blockIdx.x * kCompactItems + (int64_t)threadIdx.x * kCompactPerThread;
+// rows kept among the 64 x kCompactRounds rows of this wave (lane = row inside a run)
+__device__ __forceinline__ int compact_wave_count(const CompactArgs& a, int64_t w0, int lane) {
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < kCompactPerThread; ++k) c += (i0 + k < a.N && a.keep[i0 + k]) ? 1 : 0;
-    for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    for (int k = 0; k < kCompactRounds; ++k) {
+        const int64_t i = w0 + (int64_t)k * 64 + lane;
+        c += __popcll(__ballot(i < a.N && a.keep[i]));
+    }
+    return c;      // wave-uniform
+}
+__global__ __launch_bounds__(256) void pt_compact_count_kernel(CompactArgs a) {
+    __shared__ int s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = compact_wave_count(a, (int64_t)blockIdx.x * kCompactItems + (int64_t)wave * (64 * kCompactRounds), lane);
+    if (lane == 0) s_w[wave] = c;
     __syncthreads();
     if (threadIdx.x == 0) a.block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 __global__ __launch_bounds__(256) void pt_compact_move_kernel(CompactArgs a) {
-    __shared__ int s_w[4], s_base;
+    __shared__ int s_w[4], s_c[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // rows kept by the workgroups in front of this one
     int before = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += a.block_counts[b];
     for (int m = 1; m < 64; m <<= 1) before += __shfl_xor(before, m);
-    if (lane == 0) s_w[wave] = before;
+    const int64_t w0 = (int64_t)blockIdx.x * kCompactItems + (int64_t)wave * (64 * kCompactRounds);
+    const int mine = compact_wave_count(a, w0, lane);
+    if (lane == 0) { s_w[wave] = before; s_c[wave] = mine; }
     __syncthreads();
-    if (threadIdx.x == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
-    // this workgroup's rows: thread t owns kCompactPerThread consecutive rows
-    const int64_t i0 = (int64_t)blockIdx.x * kCompactItems + (int64_t)threadIdx.x * kCompactPerThread;
-    uint32_t mask = 0; int c = 0;
-#pragma unroll
-    for (int k = 0; k < kCompactPerThread; ++k) if (i0 + k < a.N && a.keep[i0 + k]) { mask |= 1u << k; ++c; }
-    int inc = c;
-    for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(inc, m); if (lane >= m) inc += v; }
-    __syncthreads();
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    int off = s_base + inc - c;
-    for (int w = 0; w < wave; ++w) off += s_w[w];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *a.count = off + c;
-    for (int k = 0; k < kCompactPerThread; ++k) {
-        if (!((mask >> k) & 1u)) continue;
-        const int64_t i = i0 + k, o = off++;
-        for (int j = 0; j < a.n3; ++j) {
-            f3 v = ld3(a.src3[j] + i * 3);
-            if ((a.negate3 >> j) & 1u) v = mk3(-v.x, -v.y, -v.z);
-            st3(a.dst3[j] + o * 3, v);
+    int64_t off = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    for (int w = 0; w < wave; ++w) off += s_c[w];
+    if (blockIdx.x == gridDim.x - 1 && wave == 3 && lane == 0) *a.count = (int32_t)(off + mine);
+    for (int k = 0; k < kCompactRounds; ++k) {
+        const int64_t i = w0 + (int64_t)k * 64 + lane;
+        const bool kp = i < a.N && a.keep[i];
+        const unsigned long long m = __ballot(kp);
+        if (kp) {
+            const int64_t o = off + __popcll(m & ((1ull << lane) - 1ull));
+            for (int j = 0; j < a.n3; ++j) {
+                f3 v = ld3(a.src3[j] + i * 3);
+                if ((a.negate3 >> j) & 1u) v = mk3(-v.x, -v.y, -v.z);
+                st3(a.dst3[j] + o * 3, v);
+            }
+            for (int j = 0; j < a.n1; ++j) a.dst1[j][o] = a.src1[j][i];
+            for (int j = 0; j < a.ni; ++j) a.dsti[j][o] = a.srci[j][i];
         }
-        for (int j = 0; j < a.n1; ++j) a.dst1[j][o] = a.src1[j][i];
-        for (int j = 0; j < a.ni; ++j) a.dsti[j][o] = a.srci[j][i];
+        off += __popcll(m);
     }
 }
 

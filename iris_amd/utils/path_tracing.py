@@ -468,27 +468,37 @@ def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir
             N = position.shape[0]
             if N == 0:
                 break
+            L.mark()
             if depth == 0 and mat is None:
                 mat = _mat_tensors(material_net(position))
+                L.mark("indirect: material network")
             a, r, m = mat
             s1, s2, s1b, s2b = _bounce_draws(nxt, uniforms is None, N, dev)
+            L.mark("indirect: draws")
             coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
             L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(a), L.ptr(r), L.ptr(m), L.ptr(s1), L.ptr(s2), N,
                                     L.ptr(coef1), L.ptr(e1), 1e-12, 1e-12, 0.0, L.stream()))
+            L.mark("indirect: emitter sample + visibility ray")
             L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e1), L.ptr(coef1), None, None, N, 1, L.stream()))
+            L.mark("indirect: accumulate")
             wi, pdf, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, mat, s1b, s2b, 0)
+            L.mark("indirect: BRDF sample + closest hit")
             mat_next = _mat_tensors(material_net(pos_n))
+            L.mark("indirect: material network")
             coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
             valid_next = torch.empty(N, device=dev, dtype=torch.bool)
             L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi), L.ptr(tri_n), L.ptr(mat_next[1]), L.ptr(pdf), L.ptr(w), N,
                                             L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(valid_next), 0.6, 1e-12, L.stream()))
+            L.mark("indirect: eval_emitter + MIS")
             L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e2), L.ptr(coef2), L.ptr(const2), L.ptr(w), N, 1, L.stream()))
+            L.mark("indirect: accumulate")
             if depth + 1 == indir_depth:
                 break                                                       # (the reference masks its arrays once more, :488-501, and returns)
             # continue only the paths that neither ended nor left the scene: position = position_next[valid_next], wo = -wi[valid_next], ... (:488-501)
             _, (position, normal, throughput, alb, wo), (rgh, mtl), (rows,) = compact_rows(valid_next, rows3=(pos_n, nrm_n, throughput, mat_next[0]), neg3=(wi,),
                                                                                           rows1=(mat_next[1], mat_next[2]), rowsi=(rows,))
             mat = (alb, rgh, mtl)
+            L.mark("indirect: survivors to the front (+ the count's read-back)")
     return Lacc
 
 
@@ -509,18 +519,24 @@ def _det_common(scene, emitter_net, material_net, positions, wis, normals, trian
     N = P * spp
     with torch.cuda.device(dev):
         # (the reference also evaluates the first-hit material here, :77/:157, and never uses it)
+        L.mark()
         s2 = L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(N, 2) if u is not None else torch.rand(N, 2, device=dev)
         wi, _, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, None, None, s2, lobe, roughness)
+        L.mark("first bounce: lobe sample + closest hit")
         mat_next = material_net(pos_n)
+        L.mark("first bounce: material network")
         Le, _, valid_next = emitter_net.eval_emitter(pos_n, wi, tri_n, mat_next["roughness"])        # default trace_roughness = 0.6
         # the paths that go on (:96-104 / :176-184): their state -- and the material rows just evaluated at their hits, which trace_indirect's depth 0 would ask the
         # network for a second time (:432-433) -- moved to the front on the device
         ma, mr, mm = _mat_tensors(mat_next)
         iota = torch.arange(N, device=dev, dtype=torch.int32)
         _, (p_k, n_k, a_k, wo_k), (r_k, m_k), (keep,) = compact_rows(valid_next, rows3=(pos_n, nrm_n, ma), neg3=(wi,), rows1=(mr, mm), rowsi=(iota,))
+        L.mark("first bounce: eval_emitter, survivors to the front")
         L_indir = trace_indirect(scene, emitter_net, material_net, p_k, wo_k, n_k, indir_depth, uniforms=u, mat0=(a_k, r_k, m_k) if reuse_material else None)
+        L.mark()
         total = Le.clone()
         total[keep.long()] += L_indir          # both weights multiply (Le + L_indir) of the same path
+        L.mark("sum of the path's terms")
     return sel, w, total.reshape(P, spp, 3)
 
 

@@ -55,7 +55,12 @@ def run_f1(scene, emitter, slf, dev, batch_pixels=10240, batches=8, spp=128, dep
     t0 = time.perf_counter(); f1(batches); torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / batches
     ms_mat = mat.ms() / batches
-    return {"material": material, "pixels_per_batch": bp, "spp": spp, "indir_depth": depth, "ms_per_batch": round(t * 1e3, 2), "Mpaths_per_s": round(bp * spp / t / 1e6, 1),
+    # where a batch goes: HIP events around the stages of ONE more batch (iris_amd/_lib.py StageTimer; the material network's wrapper events are not recorded here)
+    from iris_amd import _lib as L_
+    with L_.StageTimer() as tm:
+        f1(1)
+    stage_ms = {k: round(v, 3) for k, v in sorted(tm.ms().items(), key=lambda kv: -kv[1])}
+    return {"stages_ms_of_one_batch": stage_ms, "stages_sum_ms": round(sum(stage_ms.values()), 2),"material": material, "pixels_per_batch": bp, "spp": spp, "indir_depth": depth, "ms_per_batch": round(t * 1e3, 2), "Mpaths_per_s": round(bp * spp / t / 1e6, 1),
             "material_network": {"ms_per_batch": round(ms_mat, 2), "share_of_the_pass": round(ms_mat / (t * 1e3), 3), "points_per_batch": mat.points // batches,
                                  "mpoints_per_s": round(mat.points / batches / ms_mat / 1e3, 1) if ms_mat > 0 else None,
                                  "note": "every bounce evaluates the network at the (scattered) hit points of the paths still alive: 1.6 Gpoints/s is the encoding's rate on scattered positions "

@@ -15,6 +15,9 @@ line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1
 bj = json.loads(line)
 pj["rays_per_launch"] = bj["config"]["rays_per_step"]
 pj["workload"] = bj["config"]["workload"]
+if bj.get("emulated"):       # rank 0's stripes of an N-rank run, baked on one GPU (bench.py --emulate-world N): what bench.py's roofline reads at N > 1, labelled as such
+    pj["emulated_world"] = bj["emulated"]["world"]; pj["emulated_rank"] = bj["emulated"]["rank"]
+    pj["workload"] += " -- EMULATED: the stripes of rank %d of %d, on one GPU, no collective" % (bj["emulated"]["rank"], bj["emulated"]["world"])
 rows = [json.loads(l) for l in open(os.path.join(REPO, "profiles", "r2_microbench.jsonl"))]
 
 
