@@ -25,6 +25,9 @@ struct BakeArgs {
     // tile kernels only
     uint32_t* stack_ovf;        // gridDim.x * (kStackCapacity - LDS depth) * 256 dwords: traversal-stack entries beyond the LDS part
     float4* scratch;            // gridDim.x * kTileRays * (SPEC ? 2 : 1) float4: per-ray slots (sampled direction -> hit; GGX weights)
+#if IRIS_PARK
+    iris_u4v* park;             // gridDim.x * 4 waves * kParkCap records of 80 B (straggler parking, iris_trace.h)
+#endif
     unsigned int* tile_counter; // 8 counters (one per XCD, claim_tile), zeroed before the launch
     int tile_px;                // pixels per tile (tile_px * spp <= kTileRays)
 };
@@ -260,7 +263,7 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
     }
 
     // phases A-C (iris_tile.h): sample every ray (uniforms -> direction + GGX weights) and park it; sort by direction; trace
-    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true>(
+    tile_sort_trace<LAYOUT, COUNT, kTileRays, TILE_STACK, true, (IRIS_PARK != 0)>(
         a.sc, nr, s_sorted, s_stack, s_chunk, ovf, ts,
         [&](int r) -> uint32_t {
             const int pl = div_spp(r), s = r - pl * spp;
@@ -306,7 +309,11 @@ __device__ __forceinline__ void tile_body(const BakeArgs& a, int64_t p0, int np,
             } else
 #endif
             res[r] = make_float4(h.u, h.v, __int_as_float(h.slot), 0.f);
-            if (COUNT) n_rays++; });   // every ray retires once
+            if (COUNT) n_rays++; }   // every ray retires once
+#if IRIS_PARK
+        , a.park + (size_t)blockIdx.x * (kBlock / 64) * kParkCap * kParkWords4
+#endif
+        );
 
     // ---- phase D: shade every sample (hit -> p_next -> eval_emitter(p_next, wi, tri_next, ones, trace_roughness=0.0),
     // bake_shading.py:121-122, :184-185 -> Le * g) and take the per-pixel mean in the fixed order of the pixel-per-wave kernel

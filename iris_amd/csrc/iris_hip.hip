@@ -104,9 +104,10 @@ struct iris_emitter {
     int64_t n_rad = 0, k = 0;
     // Fused leaf records (round 5): the scene's leaf-record table with this emitter's ordinal of every triangle in the record's free fourth plane, so that the shading pass of
     // the bake kernels reads it from the line it fetches anyway.  Built on first use per scene (iris_bake_view), kept for the handle's life (at most two scenes).
-    struct Fused { uint64_t scene_uid; void* d_tris; };
+    struct Fused { uint64_t scene_uid; void* d_tris; hipEvent_t ready; bool done; };
     mutable std::mutex fused_mu;
     mutable std::vector<Fused> fused;
+    mutable std::vector<Fused> retired;      // tables pushed out by a third scene: a launch that was handed one may still be on its way -- freed with the handle, never earlier
 };
 
 // Launches of the one-ray-per-lane kernels (iris_intersect, the path-tracing stages below their tiling threshold) of at most this many rays run in LATENCY MODE
@@ -533,7 +534,7 @@ extern "C" IRIS_API void iris_emitter_destroy(iris_emitter* e) {
     if (!e) return;
     (void)hipFree(e->d_ord); (void)hipFree(e->d_rad); (void)hipFree(e->d_area);
     (void)hipFree(e->d_verts); (void)hipFree(e->d_cdf); (void)hipFree(e->d_ord2tri);
-    for (const auto& f : e->fused) (void)hipFree(f.d_tris);
+    for (const auto* v : {&e->fused, &e->retired}) for (const auto& f : *v) { (void)hipFree(f.d_tris); if (f.ready) (void)hipEventDestroy(f.ready); }
     delete e;
 }
 
@@ -1006,6 +1007,9 @@ static uint64_t stack_ovf_bytes() {
     return (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kStackCapacity - IRIS_TILE_STACK) * kBlock * sizeof(uint32_t);
 }
 
+static uint64_t park_bytes() {      // IRIS_PARK: wave-private pools of parked rays (iris_trace.h)
+    return IRIS_PARK ? (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks()) * (kBlock / 64) * kParkCap * kParkWords4 * 16 : 0;
+}
 extern "C" IRIS_API int iris_bake_tile_max_spp(void) { return kTileRays; }
 extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int specular) {
     if (spp < 1 || spp > kTileRays || P < 0) return 0;  // v1 kernel only
@@ -1013,7 +1017,7 @@ extern "C" IRIS_API uint64_t iris_bake_workspace_bytes(int64_t P, int spp, int s
     // (packing the pixel tensors into 48-B records was measured 7 % SLOWER than reading pos/nrm/wo directly: not done)
     // + [blocks x (96 - LDS depth) x 256 dwords: traversal-stack entries beyond the LDS part]   (specular sizing also serves iris_bake_view)
     const uint64_t blocks = (uint64_t)std::max(bake_grid_blocks(), view_grid_blocks());
-    return 256 + blocks * kTileRays * (specular ? 2 : 1) * sizeof(float4) + stack_ovf_bytes();
+    return 256 + blocks * kTileRays * (specular ? 2 : 1) * sizeof(float4) + park_bytes() + stack_ovf_bytes();
 }
 
 static const float4* fused_tris(const iris_scene* sc, const iris_emitter* em, hipStream_t st);
@@ -1049,6 +1053,9 @@ static int bake_launch(bool spec, const iris_scene* sc, const iris_emitter* em, 
         a.tile_counter = (unsigned int*)workspace;
         a.scratch = (float4*)((char*)workspace + 256);
         a.stack_ovf = (uint32_t*)((char*)workspace + need - stack_ovf_bytes());
+#if IRIS_PARK
+        a.park = (iris_u4v*)((char*)workspace + need - stack_ovf_bytes() - park_bytes());
+#endif
         HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
         if (const float4* ft = fused_tris(sc, em, st)) { a.sc.tris = ft; a.em.emit_ord = nullptr; }      // (tile kernels only: their shading pass reads the ordinal from the record)
         const int64_t n_tiles = (P + tile_px - 1) / tile_px;
@@ -1091,15 +1098,29 @@ __global__ void fuse_ord_kernel(const float4* __restrict__ src, const int32_t* _
 static const float4* fused_tris(const iris_scene* sc, const iris_emitter* em, hipStream_t st) {
     if (IRIS_NO_FUSED_RECORDS) return nullptr;
     std::lock_guard<std::mutex> lock(em->fused_mu);
-    for (const auto& f : em->fused) if (f.scene_uid == sc->uid) return (const float4*)f.d_tris;
-    if (em->fused.size() >= 2) { (void)hipFree(em->fused.front().d_tris); em->fused.erase(em->fused.begin()); }      // (a training loop uses one scene; keep the handle bounded)
-    void* d = nullptr;
+    for (auto& f : em->fused) if (f.scene_uid == sc->uid) {
+        // the table is filled by a kernel on the stream of the call that built it: a call on another stream waits for that kernel ON THE DEVICE (no host
+        // synchronisation inside a bake call -- legal under stream capture) until the event has been seen complete once
+        if (!f.done) {
+            if (hipEventQuery(f.ready) == hipSuccess) f.done = true;
+            else { (void)hipGetLastError(); if (hipStreamWaitEvent(st, f.ready, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; } }
+        }
+        return (const float4*)f.d_tris;
+    }
+    if (em->fused.size() >= 2) { em->retired.push_back(em->fused.front()); em->fused.erase(em->fused.begin()); }      // (a training loop uses one scene: the live set stays at two)
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(sc->device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }     // allocate where the scene lives, whatever the caller's current device
+    void* d = nullptr; hipEvent_t ev = nullptr;
     const int64_t n_rec = (int64_t)sc->dev.n_tris + 1;
-    if (hipMalloc(&d, (size_t)n_rec * 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    hipLaunchKernelGGL(fuse_ord_kernel, dim3(grid_for(n_rec, 256, 4096)), dim3(256), 0, st, sc->dev.tris, em->dev.emit_ord, n_rec, (float4*)d);
-    if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(d); return nullptr; }       // (once per (scene, emitter): later calls on any stream find it complete)
-    em->fused.push_back({sc->uid, d});
-    return (const float4*)d;
+    bool ok = hipMalloc(&d, (size_t)n_rec * 64) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(fuse_ord_kernel, dim3(grid_for(n_rec, 256, 4096)), dim3(256), 0, st, sc->dev.tris, em->dev.emit_ord, n_rec, (float4*)d);
+        ok = hipGetLastError() == hipSuccess && hipEventRecord(ev, st) == hipSuccess;
+    }
+    (void)hipSetDevice(prev);
+    if (!ok) { (void)hipGetLastError(); if (d) (void)hipFree(d); if (ev) (void)hipEventDestroy(ev); return nullptr; }
+    em->fused.push_back({sc->uid, d, ev, false});
+    return (const float4*)d;            // (this call's own launch follows the fill on the same stream)
 }
 extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter* em, const iris_slf* slf, const float* pos, const float* nrm,
                               const float* wo, const int32_t* pix_id, int64_t P, int n_lobes, const float* roughness, const int32_t* spp,
@@ -1120,6 +1141,9 @@ extern "C" IRIS_API int iris_bake_view(const iris_scene* sc, const iris_emitter*
     v.base.tile_counter = (unsigned int*)workspace;
     v.base.scratch = (float4*)((char*)workspace + 256);
     v.base.stack_ovf = (uint32_t*)((char*)workspace + need - stack_ovf_bytes());
+#if IRIS_PARK
+    v.base.park = (iris_u4v*)((char*)workspace + need - stack_ovf_bytes() - park_bytes());
+#endif
     v.n_lobes = n_lobes;
     const int blocks = view_grid_blocks();
     long long t = 0;

@@ -61,9 +61,9 @@ __device__ unsigned long long g_phase_cycles[8];
 // Everything exchanged through global memory here stays inside ONE workgroup, so __syncthreads() orders it (the waves of a
 // workgroup share their CU's write-through L1; an agent-scope __threadfence() would flush that L1 -- including the hot upper BVH
 // levels -- once per tile and was measured 9 % slower per fence pair).  Ends with a barrier: hits are visible to the caller.
-template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, class PhaseA, class FetchRay, class Prepare, class Retire>
+template <int LAYOUT, bool COUNT, int CAP, int TILE_STACK, bool GLOBAL_OVF, bool PARK = false, class PhaseA, class FetchRay, class Prepare, class Retire>
 __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint16_t* s_sorted, uint32_t* s_stack, int* s_chunk, uint32_t* ovf,
-                                                TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare, Retire retire) {
+                                                TraceStats& ts, PhaseA phase_a, FetchRay fetch_ray, Prepare prepare, Retire retire, iris_u4v* park_pool = nullptr) {
     static_assert(TILE_STACK * kBlock * 4 >= CAP + 2 * 256 * 4, "stack region too small to alias the sort keys");
     uint8_t* s_keys = reinterpret_cast<uint8_t*>(s_stack);
     uint32_t* s_hist = s_stack + CAP / 4;
@@ -98,6 +98,17 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
     // ---- phase C: persistent-lane traversal of the sorted list: idle lanes claim the next rays together
     {
         int my_r = 0;
+#if IRIS_PARK
+        // the idle lanes of a wave claim the next rays of the sorted list together: -> the ray's id in the tile, or -1 when the list is exhausted
+        auto claim = [&]() -> int {
+            const unsigned long long m = __ballot(1);
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_chunk, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int i = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            return i < nr ? (int)s_sorted[i] : -1;
+        };
+#endif
         auto fetch = [&](f3& o, f3& d) -> bool {
             const unsigned long long m = __ballot(1);
             int base = 0;
@@ -120,7 +131,18 @@ __device__ __forceinline__ void tile_sort_trace(const SceneDev& sc, int nr, uint
         // are spilled to vector-register lanes and read back (v_readlane + wait states) in front of the node / triangle loads of every visit.
         SceneDev sc_c = sc;
         asm volatile("" : "+s"(sc_c.nodes), "+s"(sc_c.tris), "+s"(sc_c.oct_stride));
-        trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc_c, s_stack + tid_c, tid_c, ovf, &ts, fetch, prepare, ret);
+#if IRIS_PARK
+        if constexpr (PARK && TILE_STACK >= 12) {      // (ONE instantiation of the traversal per kernel: the stage kernels of iris_pt.h do not park)
+            auto get_id = [&]() -> int { return my_r; };
+            auto set_id = [&](int id) { my_r = id; };
+            auto refetch = [&](int id, f3& o, f3& d) { fetch_ray(id, o, d); };
+            typedef __attribute__((address_space(3))) int lds_i32;        // (an LDS read: through a generic volatile pointer this is a system-coherent flat_load of a 64-bit address that gets spilled)
+            auto left = [&]() -> int { return nr - __atomic_load_n((lds_i32*)s_chunk, __ATOMIC_RELAXED); };
+            ParkOps<decltype(get_id), decltype(set_id), decltype(refetch), decltype(left), decltype(claim)> pk{park_pool + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kParkCap * kParkWords4, get_id, set_id, refetch, left, claim};      // (a SCALAR base: the wave index through readfirstlane)
+            trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc_c, s_stack + tid_c, tid_c, ovf, &ts, fetch, prepare, ret, pk);
+        } else
+#endif
+            trace_stream<LAYOUT, COUNT, TILE_STACK, GLOBAL_OVF>(sc_c, s_stack + tid_c, tid_c, ovf, &ts, fetch, prepare, ret);
         __builtin_amdgcn_s_setprio(IRIS_PRIO_D);
         IRIS_PHASE_MARK(4);      // wave 0's own traversal; 2 (below) also counts its wait for the slowest wave of the tile
     }

@@ -669,9 +669,45 @@ __device__ __forceinline__ Hit trace_bvh4(const SceneDev& sc, f3 o, f3 d, uint32
 #define IRIS_REFILL_MIN 48
 #endif
 constexpr int kRefillMin = IRIS_REFILL_MIN;
-template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire>
+// STRAGGLER PARKING (round 6, -DIRIS_PARK=1; tools/bvh_eval/wavesim `wpark+tile`).  When a wave refills, the <= 16 rays it still carries are deep in the tree and share
+// nothing with the 48 rays that start at the root: the fresh rays never reach the 44 lanes the shared scalar visit needs, and the wave keeps two populations apart
+// for the rest of their lives.  With parking the refilling wave writes those rays' traversal state -- hit so far, current reference, the LDS part of the stack and the
+// ray's id: 5 x 16 B -- to a WAVE-PRIVATE pool in the workspace (no exchange between waves: nothing to synchronise) and starts 64 fresh rays together; once the pool
+// holds a wave's worth it is taken instead of fresh rays (the stragglers run with each other), and whatever is left is taken when the list is exhausted.  A ray whose
+// stack has entries beyond the LDS part stays where it is.  Per-ray results do not change (the state is restored bit for bit; origin and direction are re-fetched).
+#ifndef IRIS_PARK
+#define IRIS_PARK 0
+#endif
+#ifndef IRIS_PARK_TAKE
+#define IRIS_PARK_TAKE 64
+#endif
+#ifndef IRIS_PARK_TAIL           // no parking once fewer than this many rays are left in the tile's list, and the pool is taken from IRIS_PARK_TAIL_TAKE records on:
+#define IRIS_PARK_TAIL 64        // the pools are then (nearly) empty when the list ends, instead of being drained at the end of the tile at a few lanes per wave
+#endif
+#ifndef IRIS_PARK_TAIL_TAKE
+#define IRIS_PARK_TAIL_TAKE 64
+#endif
+constexpr int kParkCap = 128;            // records per wave (<= 63 waiting + 16 per refill round; 5 x 16 B each)
+constexpr int kParkWords4 = 5;
+// (records are addressed as a scalar base + a 32-bit per-lane byte offset through address-space-1 pointers, like the tables: a per-lane 64-bit pointer is two
+//  registers that live across the refill round -- and were spilled to scratch there)
+typedef __attribute__((address_space(1))) iris_u4v glb_u4v_rw;
+__device__ __forceinline__ iris_u4v park_ld(const iris_u4v* base, uint32_t byte_off) { return *(glb_u4v*)(reinterpret_cast<const char*>(base) + (size_t)byte_off); }
+__device__ __forceinline__ void park_st(iris_u4v* base, uint32_t byte_off, iris_u4v v) { *(glb_u4v_rw*)(reinterpret_cast<char*>(base) + (size_t)byte_off) = v; }
+struct NoPark { static constexpr bool enabled = false; };
+template <class GetId, class SetId, class Refetch, class Left, class Claim>
+struct ParkOps {
+    static constexpr bool enabled = true;
+    iris_u4v* rec;        // this wave's records
+    GetId get_id;         // the id of the ray this lane carries
+    SetId set_id;         // ... set (an unparked ray)
+    Refetch refetch;      // (id, o, d): issue the loads of a ray's raw origin / direction again
+    Left left;            // rays left in the tile's list (wave-uniform)
+    Claim claim;          // the idle lanes claim the next rays of the list together: -> ray id, or -1
+};
+template <int LAYOUT, bool COUNT, int LDS_DEPTH, bool GLOBAL_OVF, class Fetch, class Prepare, class Retire, class Park = NoPark>
 __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_stack, uint32_t tid, uint32_t* ovf, TraceStats* ts, Fetch fetch, Prepare prepare,
-                                             Retire retire) {
+                                             Retire retire, Park park = Park()) {
     RayState r;
     r.o = mk3(0.f, 0.f, 0.f); r.d = mk3(0.f, 0.f, 1.f);
     ray_begin(sc, r, r.o, r.d);
@@ -680,15 +716,88 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
     int shared_tries = kSharedTries;   // wave-uniform: misses the shared-visit test may still have before it is skipped until the next refill
     bool live = false;             // this lane holds a ray (in flight, or finished and not yet retired)
     bool more = true;              // wave-uniform: the ray list is not exhausted
+    int n_pool = 0;                // wave-uniform: parked rays of this wave
     int max_sp = 0;
     const int kPhaseMinRt = sc.phase_min;
     for (;;) {
         // ---------------- retire finished rays, fetch and start new ones
-        const bool idle = r.cur == kEmptyRef;
-        const int n_idle = __popcll(__ballot(idle));
+        const bool idle0 = r.cur == kEmptyRef;
+        const int n_idle = __popcll(__ballot(idle0));
         if (more && (n_idle >= kRefillMin || n_idle == __popcll(__ballot(1)))) {
             bool got = false;
-            if (idle) {
+            if constexpr (Park::enabled) {
+                bool idle = idle0;
+                // ---- park what is still in flight (while the list has a wave's worth of fresh rays left), then fill ALL lanes from one source
+                const int left = park.left();
+                if (left >= IRIS_PARK_TAIL) {
+                    const bool can = !idle && st.sp <= LDS_DEPTH;
+                    const unsigned long long mp = __ballot(can);
+                    const int np = popc_mask(mp);
+                    if (np > 0 && n_pool + np <= kParkCap) {
+                        if (can) {
+                            const int slot = n_pool + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mp, 0u));
+                            const uint32_t qo = (uint32_t)slot * (kParkWords4 * 16u);
+                            iris_u4v a0 = {__float_as_uint(r.h.t), __float_as_uint(r.h.u), __float_as_uint(r.h.v), (uint32_t)r.h.slot};
+                            iris_u4v a1 = {(uint32_t)r.h.id, r.cur, (uint32_t)st.sp, (uint32_t)park.get_id()};
+                            park_st(park.rec, qo, a0); park_st(park.rec, qo + 16u, a1);
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                iris_u4v e = {st.lds[(4 * k) * kBlock], st.lds[(4 * k + 1) * kBlock], st.lds[(4 * k + 2) * kBlock], st.lds[(4 * k + 3) * kBlock]};   // (entries beyond sp: garbage nobody reads)
+                                asm volatile("" : "+v"(e));      // (four entries in flight at a time: the scheduler would otherwise read all twelve first)
+                                park_st(park.rec, qo + 32u + 16u * k, e);
+                            }
+                            r.cur = kEmptyRef; live = false; idle = true;
+                        }
+                        n_pool += np;
+                    }
+                }
+                const bool from_pool = n_pool >= IRIS_PARK_TAKE || (left < IRIS_PARK_TAIL && n_pool >= IRIS_PARK_TAIL_TAKE) || (left <= 0 && n_pool > 0);
+                int uslot = -1;            // the record an unparked lane restores from (read in two steps: few registers live across ray_begin)
+                int id = -1;               // the ray this lane starts: from the pool or from the list -- ONE place below issues its loads
+                if (from_pool) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the records were written by other LANES of this wave, rounds ago: their stores are waited for HERE, once per take, not at every parking
+                    const unsigned long long mi = __ballot(idle);
+                    if (idle) {
+                        if (live) retire(r.h);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                        if (rank < n_pool) {
+                            uslot = n_pool - 1 - rank;
+                            const uint32_t qo = (uint32_t)uslot * (kParkWords4 * 16u);
+                            id = (int)park_ld(park.rec, qo + 16u).w;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {      // the stack goes straight back to this lane's LDS column, four entries at a time
+                                iris_u4v e = park_ld(park.rec, qo + 32u + 16u * k);
+                                asm volatile("" : "+v"(e));
+                                st.lds[(4 * k) * kBlock] = e.x; st.lds[(4 * k + 1) * kBlock] = e.y; st.lds[(4 * k + 2) * kBlock] = e.z; st.lds[(4 * k + 3) * kBlock] = e.w;
+                            }
+                        }
+                    }
+                    n_pool -= min(n_pool, popc_mask(mi));
+                } else if (idle) {
+                    if (live) retire(r.h);
+                    id = park.claim();
+                }
+                f3 o_ = mk3(0.f, 0.f, 0.f), d_ = mk3(0.f, 0.f, 1.f);      // (locals, dead at the end of the round: as members of the loop-carried state they were spilled around the restore below)
+                if (idle) {
+                    live = got = id >= 0;
+                    if (got) { park.set_id(id); park.refetch(id, o_, d_); }
+                }
+                if (__ballot(got) == 0 && n_pool == 0) more = false;
+                shared_tries = kSharedTries;
+                if (got) {
+                    prepare(o_, d_);
+                    ray_begin(sc, r, o_, d_);
+                    st.sp = 0;
+                    if (uslot >= 0) {
+                        const uint32_t qo = (uint32_t)uslot * (kParkWords4 * 16u);
+                        const iris_u4v a0 = park_ld(park.rec, qo), a1 = park_ld(park.rec, qo + 16u);
+                        r.h.t = __uint_as_float(a0.x); r.h.u = __uint_as_float(a0.y); r.h.v = __uint_as_float(a0.z); r.h.slot = (int)a0.w;
+                        r.h.id = (int)a1.x; r.cur = a1.y; st.sp = (int)a1.z;
+                    }
+                    if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
+                }
+            } else {
+            if (idle0) {
                 if (live) retire(r.h);
                 live = got = fetch(r.o, r.d);
             }
@@ -699,6 +808,7 @@ __device__ __forceinline__ void trace_stream(const SceneDev& sc, uint32_t* lds_s
                 ray_begin(sc, r, r.o, r.d);
                 st.sp = 0;
                 if (COUNT) { ts->sp_gt8 += max_sp > 8; ts->sp_gt12 += max_sp > 12; ts->sp_gt16 += max_sp > 16; max_sp = 0; }
+            }
             }
         }
         if (__ballot(r.cur != kEmptyRef) == 0) {

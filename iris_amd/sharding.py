@@ -14,6 +14,8 @@ import torch.distributed as dist
 # 1080 rows: 135 stripes -> 17 | 16 per rank at N = 8 (max/mean 1.007); 16-row stripes give 144 vs 128 rows (1.067).  IRIS_STRIPE_ROWS: experiments only
 # (tools/emulate_ranks.sh; every rank of a job must see the same value)
 STRIPE_ROWS = int(os.environ.get("IRIS_STRIPE_ROWS", "8"))
+if STRIPE_ROWS < 1:
+    raise ValueError(f"IRIS_STRIPE_ROWS={STRIPE_ROWS}: a stripe has at least one row")
 
 
 def stripe_rows(H, world, rank, stripe=STRIPE_ROWS):
@@ -57,6 +59,16 @@ class MapGatherer:
         # tests/test_rccl_world1.py: RCCL, dist.gather with a list of views, all_gather_into_tensor and iris_unstripe_maps on an RCCL-written buffer
         # exercised on a one-GPU box)
         self.collective = world > 1 or bool(force_collective)
+        if stripe < 1:
+            raise ValueError("MapGatherer: stripe height must be >= 1")
+        if world > 1:
+            # every rank must cut the image into the same stripes (IRIS_STRIPE_ROWS is read per process): a mismatch would send rows the receiver puts elsewhere
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                probe = torch.tensor([stripe, -stripe], dtype=torch.int64, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+                if int(probe[0]) != stripe or int(-probe[1]) != stripe:
+                    raise ValueError(f"MapGatherer: ranks disagree on the stripe height (this rank: {stripe}, max {int(probe[0])}, min {int(-probe[1])})")
         self.n_local = int(stripe_rows(H, world, rank, stripe).numel()) * W
         self.n_max = max_local_pixels(H, W, world, stripe)
         self.receives = self.collective and (mode == "all_gather" or rank == 0)

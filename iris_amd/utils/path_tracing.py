@@ -250,7 +250,11 @@ def _path_tracing(scene, emitter_net, material_net, rays_o, rays_d, dx_du, dy_dv
         raise L.IrisError("path_tracing: the continuation (trace_indirect) compacts its paths; compact=False is for path_tracing_single")
     u = list(uniforms) if uniforms is not None else None
     trace_rough = 0.6 if full else 0.0
-    rough_min = getattr(material_net, "roughness_min", None)
+    # the bound is taken from a network that is EXACTLY NGPBRDF (a subclass may map its roughness otherwise and would inherit the class attribute silently) or that
+    # declares one on the INSTANCE (an explicit opt-in: tools/bench_refine.py's timing wrapper copies its network's).  Caveat: with a non-finite network output the
+    # reference's test `NaN > 0` is False where the skipped path takes it for True: the "same bits" claim holds for finite outputs.
+    from ..model.brdf import NGPBRDF
+    rough_min = NGPBRDF.roughness_min if type(material_net) is NGPBRDF else getattr(material_net, "__dict__", {}).get("roughness_min")
     skip_next = bool(skip_unused_material) and rough_min is not None and float(rough_min) > trace_rough     # (see path_tracing_single's docstring)
     if u is not None:
         nxt = lambda *shape: L.require_gpu(u.pop(0), torch.float32, "uniforms").reshape(*shape)             # noqa: E731

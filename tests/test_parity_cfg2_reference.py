@@ -129,6 +129,14 @@ def test_hip_vs_reference_python_cfg2_size(oracle_mod):
         else:
             hip = bs.bake_specular(scene, emitter, pos, nrm, wo, fx.rough[lobe - 1], fx.spp, seed=fx.seed, stream_id=lobe, pix_id=pix, want_tri=True, want_src=True)
         hip = [t.cpu().numpy() for t in hip]
+        # the SHIPPED path: without per-sample outputs a retiring ray resolves its own hit and the shading pass takes two rounds of a pixel side by side (iris_bake.h
+        # tile_body, `resolve`); asking for the triangle ids above selects the plain (u, v, slot) loop.  The maps must be the same bits: the table below is the timed path's.
+        if lobe == 0:
+            plain = (bs.bake_diffuse(scene, emitter, pos, nrm, fx.spp, seed=fx.seed, stream_id=0, pix_id=pix),)
+        else:
+            plain = bs.bake_specular(scene, emitter, pos, nrm, wo, fx.rough[lobe - 1], fx.spp, seed=fx.seed, stream_id=lobe, pix_id=pix)
+        for a, b in zip(plain, hip):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
         dev = fx.predictor(lobe)
         for a, b in zip(hip, dev):                                             # (i) bit for bit: maps, per-sample triangles, per-sample table rows
             np.testing.assert_array_equal(a, b)
