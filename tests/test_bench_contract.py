@@ -118,6 +118,36 @@ def test_eight_ranks_on_one_gpu_line():
     assert 0.5 * rays < d["config"]["rays_per_step"] <= rays                      # strong scaling: ONE view per step, whatever N
 
 
+@pytest.mark.timeout(1500)
+def test_eight_ranks_full_size_line_is_complete():
+    """BASELINE configs[3] as the driver will run it -- `bench.py --gpus 8`, 1920 x 1080, SPP 128, the 1.0 M-triangle room -- with the eight ranks sharing this box's
+    one GPU over gloo (functional, never a measurement): the line rank 0 prints must be as complete as the N = 1 line -- `roofline` with a fraction (the counters of
+    rank 0's stripes: profiles/pmc_r6_world8.json, taken with --emulate-world 8 and labelled so; a profile of other kernel sources is refused with the reason),
+    `cpu_baseline` (run by rank 0 after the timed region), the parity check of the timed maps, the gathered image equal to what the ranks sent."""
+    import time
+    env = dict(os.environ, IRIS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "3", "--cpu-repeats", "1", "--no-extras"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["rays_per_step"] == 1920 * 1080 * 128 * 7
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen_by_all_reduce"] == 8 and mg["gathered_image_matches_what_the_ranks_sent"] is True and mg["collective"] == "gather"
+    assert d["parity_check"]["bit_exact"] is True
+    rl = d["roofline"]
+    assert rl["rays_per_launch"] == 17 * 8 * 1920 * 128 * 7                      # rank 0 owns 17 of the 135 stripes of 8 rows
+    if rl["frac"] is None:
+        assert "stale" in rl["pmc_source"], rl["pmc_source"]                      # the committed counters are of other kernel sources: refused, with the reason
+    else:
+        assert rl["pmc_file"] == "profiles/pmc_r6_world8.json" and "emulate-world 8" in rl["pmc_source"] and 0.3 < rl["frac"] <= 1.0 and rl["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and d["gpu_over_cpu"] > 0
+    print("eight ranks, full size: %.0f s" % (time.time() - t0), rl["frac"], rl["pmc_source"], cb["value"])
+
+
 @pytest.mark.timeout(900)
 def test_two_ranks_sharded_by_views():
     """SURVEY 8(e)'s fallback for the view sequence: whole views per rank, no collective, weak scaling"""
