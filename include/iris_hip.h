@@ -206,6 +206,13 @@ IRIS_API int iris_pt_brdf_trace(const iris_scene *, const float *pos, const floa
                        const float *roughness, const float *metallic, const float *s1, const float *s2, int64_t N, float *wi,
                        float *pdf, float *weight, float *pos_next, float *nrm_next, int64_t *tri_next, uint8_t *valid,
                        int lobe, float lobe_roughness, iris_stream_t);
+/* trace_indirect's two tracing stages of a bounce (utils/path_tracing.py:434-471) in ONE launch: iris_pt_nee with the draws (s1, s2) and iris_pt_brdf_trace
+ * (lobe 0: sample_brdf) with the draws (s1b, s2b) on the same N paths -- the visibility ray and the BRDF ray of a path leave from the same point; their rays are
+ * sorted by direction together and traced by the same persistent lanes.  Outputs as the two calls' (same bits). */
+IRIS_API int iris_pt_bounce(const iris_scene *, const iris_emitter *, const float *pos, const float *nrm, const float *wo, const float *albedo,
+                   const float *roughness, const float *metallic, const float *s1, const float *s2, const float *s1b, const float *s2b, int64_t N,
+                   float *coef1, int32_t *e1, float g_eps, float pdf_eps, float mis_eps, float *wi, float *pdf, float *weight, float *pos_next,
+                   float *nrm_next, int64_t *tri_next, uint8_t *valid, iris_stream_t);
 /* :394-404  eval_emitter(..., mat_next.roughness, 0.0) + geometry term + MIS -> term2 = coef2 * radiance[e2] + const2.
  * roughness_next may be NULL: "every roughness exceeds trace_roughness" -- the only use of mat_next in the reference's path_tracing_single is the test
  * roughness > trace_roughness = 0.0 (model/emitter.py:209), and NGPBRDF's roughness is sigmoid * 0.98 + 0.02 >= 0.02 (model/brdf.py:258): a caller that knows its

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "iris_pt_brdf_finish": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _F, _F, _P],
     "iris_pt_primary": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "iris_pt_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
+    "iris_pt_bounce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "iris_pt_compact_workspace_bytes": [_I64],
     "iris_pt_compact": [_P, _I64, _I32, _P, _P, C.c_uint32, _I32, _P, _P, _I32, _P, _P, _P, _P, C.c_uint64, _P],
     "iris_pt_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P],

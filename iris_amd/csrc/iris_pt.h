@@ -93,6 +93,7 @@ struct PtArgs {
     int64_t N;
     const float *pos, *nrm, *wo, *albedo, *rough, *metal;   // (N,3),(N,3),(N,3),(N,3),(N),(N)
     const float *s1, *s2;                                    // (N),(N,2) uniforms
+    const float *s1b, *s2b;                                  // pt_bounce_kernel: the BRDF stage's draws (s1 / s2 are the emitter-sampling stage's)
     // NEE outputs
     float* coef1; int32_t* e1;
     // BRDF-sample outputs
@@ -177,18 +178,19 @@ __global__ __launch_bounds__(kBlock, JOINT ? IRIS_JOINT_WAVES : 1) void pt_nee_k
 
 // utils/path_tracing.py:384-392: BRDF sampling + next intersection
 // direction, pdf and weight of ray i (lobe 0: sample_brdf; 1: sample_diffuse; 2: sample_specular at lobe_rough)
-__device__ __forceinline__ void pt_sample_dir(const PtArgs& a, int64_t i, f3 wo, f3 n, f3& wi, float& pdf, f3& w) {
+__device__ __forceinline__ void pt_sample_dir(const PtArgs& a, int64_t i, f3 wo, f3 n, f3& wi, float& pdf, f3& w, const float* s1 = nullptr, const float* s2 = nullptr) {
+    if (!s2) { s1 = a.s1; s2 = a.s2; }
     if (a.lobe == 0) {
-        sample_brdf1(a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
+        sample_brdf1(s1[i], s2[i * 2], s2[i * 2 + 1], wo, n, load_mat(a, i), wi, pdf, w);
     } else {
         f3 t, b;
         normal_space(n, t, b);
         if (a.lobe == 1) {                                   // BaseBRDF.sample_diffuse (model/brdf.py:78-88)
-            wi = diffuse_sampler(a.s2[i * 2], a.s2[i * 2 + 1], n, t, b);
+            wi = diffuse_sampler(s2[i * 2], s2[i * 2 + 1], n, t, b);
             pdf = relu(t_dot(n, wi)) / kPi;
             w = mk3(1.f, 1.f, 1.f);
         } else {                                             // BaseBRDF.sample_specular (model/brdf.py:112-136)
-            wi = specular_sampler(a.s2[i * 2], a.s2[i * 2 + 1], a.lobe_rough, wo, n, t, b);
+            wi = specular_sampler(s2[i * 2], s2[i * 2 + 1], a.lobe_rough, wo, n, t, b);
             SpecW sw = specular_weights(wi, wo, n, a.lobe_rough, true);
             pdf = sw.pdf;
             w = mk3(sw.g0, sw.g1, 0.f);
@@ -284,6 +286,67 @@ __global__ __launch_bounds__(kBlock, IRIS_PT_WAVES) void pt_tiled_kernel(PtArgs 
                 pt_nee_finish(a, i, x, ld3(a.nrm + i * 3), ld3(a.wo + i * 3), wi, emit_pdf, emit_tri, a.e1[i], rec[i * 3], rec[i * 3 + 1]);
             } else {
                 const f3 h = ld3(rec + i * 3);
+                pt_next_hit(a, i, ld3(a.wi_out + i * 3), __float_as_int(h.z), h.x, h.y);
+            }
+        }
+    }
+}
+
+// Both ray kinds of a bounce behind ONE launch (round 6; trace_indirect, utils/path_tracing.py:434-471): the emitter-sampling stage's visibility ray and the BRDF
+// stage's ray of a path leave from the same point, and a whole-image bounce of refine_shading's reference batch (1.3 M paths) cut into two launches leaves each
+// with 512-ray tiles.  A tile here is np PATHS = 2 np rays -- ray r < np: the emitter-sampling ray of path i0 + r, ray r >= np: the BRDF ray of path i0 + r - np --
+// sorted by direction TOGETHER and traced by the same persistent lanes; the parked values and the epilogues are those of pt_tiled_kernel<NEE> and <!NEE>: same bits.
+template <int LAYOUT>
+__global__ __launch_bounds__(kBlock, IRIS_PT_WAVES) void pt_bounce_kernel(PtArgs a, int tile_paths) {
+    __shared__ uint16_t s_sorted[kPtTileCap];
+    __shared__ uint32_t s_stack[kPtTileStack * kBlock];
+    __shared__ int s_chunk;
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (a.N + tile_paths - 1) / tile_paths;
+    TraceStats ts;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        if (tid == 0) s_chunk = 0;
+        (s_stack + kPtTileCap / 4)[tid] = 0;
+        __syncthreads();
+        const int64_t i0 = tile * tile_paths;
+        const int np = (int)min((int64_t)tile_paths, a.N - i0);
+        tile_sort_trace<LAYOUT, false, kPtTileCap, kPtTileStack, false>(
+            a.sc, 2 * np, s_sorted, s_stack, &s_chunk, nullptr, ts,
+            [&](int r) -> uint32_t {
+                const bool brdf = r >= np;
+                const int64_t i = i0 + (brdf ? r - np : r);
+                f3 wi;
+                if (!brdf) {
+                    float emit_pdf; int64_t emit_tri;
+                    sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], ld3(a.pos + i * 3), wi, emit_pdf, emit_tri);
+                    st3(a.coef1 + i * 3, wi);
+                } else {
+                    f3 w; float pdf;
+                    pt_sample_dir(a, i, ld3(a.wo + i * 3), ld3(a.nrm + i * 3), wi, pdf, w, a.s1b, a.s2b);
+                    a.brdf_pdf[i] = pdf; st3(a.brdf_w + i * 3, w);
+                    st3(a.wi_out + i * 3, wi);
+                }
+                return dir_bin(wi);
+            },
+            [&](int r, f3& o, f3& d) { const bool brdf = r >= np; const int64_t i = i0 + (brdf ? r - np : r); o = ld3(a.pos + i * 3); d = ld3((brdf ? a.wi_out : a.coef1) + i * 3); },
+            [&](f3& o, f3& d) { o = mk3(o.x + kRayEps * d.x, o.y + kRayEps * d.y, o.z + kRayEps * d.z); },
+            [&](int r, const Hit& h) {
+                const bool brdf = r >= np;
+                const int64_t i = i0 + (brdf ? r - np : r);
+                if (!brdf) { a.coef1[i * 3] = h.u; a.coef1[i * 3 + 1] = h.v; a.e1[i] = h.slot; }
+                else st3(a.pos_next + i * 3, mk3(h.u, h.v, __int_as_float(h.slot)));
+            });
+        for (int r = tid; r < 2 * np; r += kBlock) {
+            const bool brdf = r >= np;
+            const int64_t i = i0 + (brdf ? r - np : r);
+            if (!brdf) {
+                const f3 x = ld3(a.pos + i * 3);
+                f3 wi; float emit_pdf; int64_t emit_tri;
+                sample_emitter1(a.es, a.s1[i], a.s2[i * 2], a.s2[i * 2 + 1], x, wi, emit_pdf, emit_tri);   // (the direction slot now holds u, v)
+                pt_nee_finish(a, i, x, ld3(a.nrm + i * 3), ld3(a.wo + i * 3), wi, emit_pdf, emit_tri, a.e1[i], a.coef1[i * 3], a.coef1[i * 3 + 1]);
+            } else {
+                const f3 h = ld3(a.pos_next + i * 3);
                 pt_next_hit(a, i, ld3(a.wi_out + i * 3), __float_as_int(h.z), h.x, h.y);
             }
         }

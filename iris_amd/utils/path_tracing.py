@@ -413,6 +413,35 @@ class _Counts:
         return int(h[0])
 
 
+class _Pool:
+    """Several per-path arrays of a bounce out of ONE allocation (a float32 block cut into views, every piece starting at a multiple of 4 floats; int32 / int64 / bool
+    pieces are views of the same block): a bounce of trace_indirect needs ~25 arrays, and at the reference's batch size the host thread that allocates and launches is as
+    long as the kernels."""
+
+    def __init__(self, n_floats, device):
+        self.buf, self.off = torch.empty(int(n_floats) + 64, device=device, dtype=torch.float32), 0
+
+    def _take(self, n_floats):
+        o = self.off
+        self.off = (o + int(n_floats) + 3) // 4 * 4
+        if o + int(n_floats) > self.buf.numel():
+            raise L.IrisError("_Pool: block too small for its pieces (a sizing bug)")
+        return self.buf[o:o + int(n_floats)]
+
+    def f(self, *shape):
+        return self._take(math.prod(shape)).view(*shape)
+
+    def i32(self, n):
+        return self._take(n).view(torch.int32)
+
+    def i64(self, n):
+        self.off = (self.off + 1) // 2 * 2
+        return self._take(2 * n).view(torch.int64)
+
+    def u8(self, n, dtype=torch.bool):
+        return self._take((n + 3) // 4).view(torch.uint8)[:n].view(dtype)
+
+
 def compact_rows(keep, rows3=(), neg3=(), rows1=(), rowsi=()):
     """Boolean indexing of several per-path arrays by one mask, as ONE order-preserving device-side pass (`iris_pt_compact`): returns (count, [a[keep] for a in rows3] +
     [-a[keep] for a in neg3], [a[keep] for a in rows1], [a[keep] for a in rowsi]) -- the outputs are views of N-row buffers cut to the count (one 4-byte read-back)."""
@@ -424,10 +453,11 @@ def compact_rows(keep, rows3=(), neg3=(), rows1=(), rowsi=()):
     ini = [L.require_gpu(t, torch.int32, "rowsi").reshape(N) for t in rowsi]
     if max(len(in3), len(in1), len(ini)) > 6:
         raise L.IrisError("compact_rows: at most 6 arrays of each kind")
-    out3 = [torch.empty(N, 3, device=dev) for _ in in3]; out1 = [torch.empty(N, device=dev) for _ in in1]; outi = [torch.empty(N, device=dev, dtype=torch.int32) for _ in ini]
-    count = torch.empty(1, device=dev, dtype=torch.int32)
     ws_bytes = int(L.lib().iris_pt_compact_workspace_bytes(N))
-    ws = torch.empty(max(ws_bytes, 4), device=dev, dtype=torch.uint8)
+    pool = _Pool((3 * len(in3) + len(in1) + len(ini)) * N + 4 * (len(in3) + len(in1) + len(ini)) + ws_bytes // 4 + 64, dev)
+    out3 = [pool.f(N, 3) for _ in in3]; out1 = [pool.f(N) for _ in in1]; outi = [pool.i32(N) for _ in ini]
+    count = pool.i32(1)
+    ws = pool.u8(max(ws_bytes, 4), torch.uint8)
     arr = lambda ts: (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])          # noqa: E731
     neg = sum(1 << (len(rows3) + k) for k in range(len(neg3)))
     with torch.cuda.device(dev):
@@ -479,18 +509,22 @@ def trace_indirect(scene, emitter_net, material_net, position, wo, normal, indir
             a, r, m = mat
             s1, s2, s1b, s2b = _bounce_draws(nxt, uniforms is None, N, dev)
             L.mark("indirect: draws")
-            coef1 = torch.empty(N, 3, device=dev); e1 = torch.empty(N, device=dev, dtype=torch.int32)
-            L.check(lib.iris_pt_nee(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(a), L.ptr(r), L.ptr(m), L.ptr(s1), L.ptr(s2), N,
-                                    L.ptr(coef1), L.ptr(e1), 1e-12, 1e-12, 0.0, L.stream()))
-            L.mark("indirect: emitter sample + visibility ray")
+            pool = _Pool(28 * N + 256, dev)                      # every per-path array of the bounce out of one allocation (26.5 N floats + padding)
+            coef1 = pool.f(N, 3); e1 = pool.i32(N)
+            # the emitter-sampling stage (sample_emitter, visibility ray, geometry term, eval_brdf, MIS: :434-456) and the BRDF stage (sample_brdf + closest hit, :459-465) of
+            # the bounce as ONE launch: the two rays of a path leave from the same point, and their rays are sorted and traced together (iris_pt_bounce)
+            wi = pool.f(N, 3); pdf = pool.f(N); w = pool.f(N, 3)
+            pos_n = pool.f(N, 3); nrm_n = pool.f(N, 3)
+            tri_n = pool.i64(N); hit = pool.u8(N)
+            L.check(lib.iris_pt_bounce(scene.handle, eh, L.ptr(position), L.ptr(normal), L.ptr(wo), L.ptr(a), L.ptr(r), L.ptr(m), L.ptr(s1), L.ptr(s2), L.ptr(s1b), L.ptr(s2b), N,
+                                       L.ptr(coef1), L.ptr(e1), 1e-12, 1e-12, 0.0, L.ptr(wi), L.ptr(pdf), L.ptr(w), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(tri_n), L.ptr(hit), L.stream()))
+            L.mark("indirect: emitter sample + visibility ray, BRDF sample + closest hit (one launch)")
             L.check(lib.iris_pt_apply(L.ptr(Lacc), L.ptr(rows), L.ptr(throughput), L.ptr(radiance), L.ptr(e1), L.ptr(coef1), None, None, N, 1, L.stream()))
             L.mark("indirect: accumulate")
-            wi, pdf, w, pos_n, nrm_n, tri_n = _lobe_trace(scene, position, normal, wo, mat, s1b, s2b, 0)
-            L.mark("indirect: BRDF sample + closest hit")
             mat_next = _mat_tensors(material_net(pos_n))
             L.mark("indirect: material network")
-            coef2 = torch.empty(N, 3, device=dev); const2 = torch.empty(N, 3, device=dev); e2 = torch.empty(N, device=dev, dtype=torch.int32)
-            valid_next = torch.empty(N, device=dev, dtype=torch.bool)
+            coef2 = pool.f(N, 3); const2 = pool.f(N, 3); e2 = pool.i32(N)
+            valid_next = pool.u8(N)
             L.check(lib.iris_pt_brdf_finish(eh, sh, L.ptr(position), L.ptr(pos_n), L.ptr(nrm_n), L.ptr(wi), L.ptr(tri_n), L.ptr(mat_next[1]), L.ptr(pdf), L.ptr(w), N,
                                             L.ptr(coef2), L.ptr(const2), L.ptr(e2), L.ptr(valid_next), 0.6, 1e-12, L.stream()))
             L.mark("indirect: eval_emitter + MIS")

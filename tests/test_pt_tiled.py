@@ -59,6 +59,46 @@ def test_tiled_stages_equal_plain_kernels(tmp_path, N):
     assert int((plain[5] >= 0).sum()) > 0 or N == 1            # next-hit triangle ids are exercised
 
 
+@pytest.mark.parametrize("N", [1, 100, 129, 4096, 70001])
+def test_one_launch_bounce_equals_the_two_stages(tmp_path, N):
+    """iris_pt_bounce (trace_indirect's emitter-sampling stage and BRDF stage of a bounce behind ONE launch: 2 N rays sorted and traced together) against the two stage calls,
+    every output bit for bit -- through the merged tile kernel (pt_tile_min = 1) and through its small-call fall-back."""
+    from test_pt_single import _gpu_setup
+    from iris_amd import _lib as L
+    dev = torch.device("cuda:0")
+    _, _, sc, em = _gpu_setup(tmp_path, dev)
+    g = torch.Generator(device="cpu").manual_seed(N)
+    R = lambda *s: torch.rand(*s, generator=g).to(dev)
+    pos = (R(N, 3) * torch.tensor([3.6, 2.6, 2.2], device=dev) + 0.2).contiguous()
+    nrm = torch.nn.functional.normalize(R(N, 3) - 0.5, dim=-1).contiguous()
+    wo = torch.nn.functional.normalize(nrm + 0.8 * (R(N, 3) - 0.5), dim=-1).contiguous()
+    albedo, rough, metal = R(N, 3).contiguous(), (R(N) * 0.9 + 0.05).contiguous(), R(N).contiguous()
+    s1, s2, s1b, s2b = R(N), R(N, 2), R(N), R(N, 2)
+
+    def outs():
+        return ([torch.empty(N, 3, device=dev), torch.empty(N, device=dev, dtype=torch.int32)],
+                [torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev),
+                 torch.empty(N, device=dev, dtype=torch.int64), torch.empty(N, device=dev, dtype=torch.bool)])
+    lib = L.lib()
+    for tile_min in (1 << 40, 1):
+        L.debug_set("pt_tile_min", tile_min)
+        try:
+            a1, b1 = outs()
+            with torch.cuda.device(dev):
+                L.check(lib.iris_pt_nee(sc.handle, em.handle(dev), L.ptr(pos), L.ptr(nrm), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), N,
+                                        L.ptr(a1[0]), L.ptr(a1[1]), 1e-12, 1e-12, 0.0, L.stream()))
+                L.check(lib.iris_pt_brdf_trace(sc.handle, L.ptr(pos), L.ptr(nrm), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1b), L.ptr(s2b), N,
+                                               *[L.ptr(t) for t in b1], 0, 0.0, L.stream()))
+                a2, b2 = outs()
+                L.check(lib.iris_pt_bounce(sc.handle, em.handle(dev), L.ptr(pos), L.ptr(nrm), L.ptr(wo), L.ptr(albedo), L.ptr(rough), L.ptr(metal), L.ptr(s1), L.ptr(s2), L.ptr(s1b), L.ptr(s2b), N,
+                                           L.ptr(a2[0]), L.ptr(a2[1]), 1e-12, 1e-12, 0.0, *[L.ptr(t) for t in b2], L.stream()))
+            for k, (x, y) in enumerate(zip(a1 + b1, a2 + b2)):
+                assert torch.equal(x, y), (tile_min, k)
+        finally:
+            L.debug_set("pt_tile_min", -1)
+    assert N < 4096 or (int((b1[5] >= 0).sum()) > 0 and int((a1[1] >= 0).sum()) > 0)       # hits and visible emitters are exercised
+
+
 def test_refine_and_pt_single_parity_through_tiles(tmp_path, oracle_mod, force_tiles):
     import test_refine, test_pt_single
     test_refine.test_hip_refine(tmp_path, oracle_mod)
