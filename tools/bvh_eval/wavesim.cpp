@@ -32,7 +32,7 @@ static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 static constexpr uint32_t kLeaf = 0x80000000u, kEmpty = 0xffffffffu;
-static int kRefillMin = 48, kPhaseMin = 12, kScalarTop = 44, kSharedTries = 2;   // the kernel's constants (iris_trace.h); WAVESIM_REFILL / _PHASE / _TOP / _TRIES override them
+static int kRefillMin = 48, kRefillTop = 0 /* 0: = kRefillMin */, kPhaseMin = 12, kPhaseMinLeaf = 0 /* 0: = kPhaseMin */, kScalarTop = 44, kSharedTries = 2;   // the kernel's constants (iris_trace.h); WAVESIM_REFILL / _PHASE / _TOP / _TRIES override them
 
 struct QNode { float lo[4][3], hi[4][3]; uint32_t ref[4]; };   // decoded (quantised, conservative) child boxes; ref: node index or kLeaf | start << 3 | count; unused: inverted box
 
@@ -153,7 +153,7 @@ struct Sim {
                 int n_idle = 0;
                 for (auto& L : w.l) n_idle += is_idle(L);
                 bool stepped = false;
-                if (w.more && (n_idle >= kRefillMin || n_idle == 64)) {
+                if (w.more && (n_idle >= (kRefillTop ? kRefillTop : kRefillMin) || n_idle == 64)) {
                     bool any = false;
                     if (parking) {
                         // PARKING (round 6 study): a refilling wave hands the rays it still carries to a pool and starts 64 fresh rays together; when the pool holds a
@@ -217,7 +217,7 @@ struct Sim {
             {   // leaf phase
                 int n_node = 0, n_leaf = 0, n_idle = 0;
                 for (auto& L : w.l) { if (at_leaf(L)) ++n_leaf; else if (at_node(L)) ++n_node; else ++n_idle; }
-                if (n_leaf == 0 || (n_leaf < kPhaseMin && n_node >= kPhaseMin) || (n_leaf <= 64 - kRefillMin && w.more && n_idle >= kRefillMin)) { w.phase = 0; continue; }
+                if (n_leaf == 0 || (n_leaf < (kPhaseMinLeaf ? kPhaseMinLeaf : kPhaseMin) && n_node >= (kPhaseMinLeaf ? kPhaseMinLeaf : kPhaseMin)) || (n_leaf <= 64 - kRefillMin && w.more && n_idle >= kRefillMin)) { w.phase = 0; continue; }
                 uint32_t keys[64]; int nk = 0;
                 for (auto& L : w.l) if (at_leaf(L)) keys[nk++] = (L.cur & 0x7fffffffu) >> 3;
                 std::sort(keys, keys + nk);
@@ -259,6 +259,8 @@ int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: wavesim room.bin block_rays.bin scheme...\n"); return 1; }
     if (getenv("WAVESIM_REFILL")) kRefillMin = atoi(getenv("WAVESIM_REFILL"));
     if (getenv("WAVESIM_PHASE")) kPhaseMin = atoi(getenv("WAVESIM_PHASE"));
+    if (getenv("WAVESIM_REFILL_TOP")) kRefillTop = atoi(getenv("WAVESIM_REFILL_TOP"));        // the refill test at the top of a round (where the wave is anyway) against the early exit from a phase
+    if (getenv("WAVESIM_PHASE_LEAF")) kPhaseMinLeaf = atoi(getenv("WAVESIM_PHASE_LEAF"));     // the early exit of the LEAF phase on its own
     if (getenv("WAVESIM_TOP")) kScalarTop = atoi(getenv("WAVESIM_TOP"));
     if (getenv("WAVESIM_TRIES")) kSharedTries = atoi(getenv("WAVESIM_TRIES"));
     Scene sc;
