@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end wall clock of the bake_shading CLI (reference: bake_shading.py as run by scripts/*/train.sh): the bench workload written
-to disk in the reference's file formats (scene.ply, vslf.npz, emitter.pth, camera JSON), then `python -m iris_amd.bake_shading` over a
+to disk in the reference's file formats and ScanNet++ layout (data/<scene>/scans/scene.ply, data/<scene>/psdf/{train_test_lists,transforms_all}.json, vslf.npz, emitter.pth), then `python -m iris_amd.bake_shading` over a
 sequence of 1080p views -- mesh load + BVH build, per view rays / primary hits / 7-lobe bake / denoise, 13 EXR files per view.
 bench.py times the path with inputs resident in HBM; this is the number a user of the CLI sees.  One JSON line per configuration.
 
@@ -44,7 +44,9 @@ def main():
     args = ap.parse_args()
     from tools import synth
     shutil.rmtree(args.out, ignore_errors=True)
-    scene_dir = os.path.join(args.out, "scene"); os.makedirs(scene_dir)
+    SCENE = "bench0room"                                               # the ScanNet++ layout the reference's scripts run on: <root>/data/<scene>/{scans/scene.ply, psdf/*.json}
+    scene_dir = os.path.join(args.out, "data", SCENE, "scans"); os.makedirs(scene_dir)
+    psdf_dir = os.path.join(args.out, "data", SCENE, "psdf"); os.makedirs(psdf_dir)
     t0 = time.time()
     room = synth.room(1, args.tris)
     v, f = room["vertices"].astype(np.float32), room["faces"].astype(np.int32)
@@ -60,19 +62,24 @@ def main():
                 "emitter_area": torch.from_numpy(emi["emitter_area"]), "emitter_normal": torch.zeros(len(emi["emitter_area"]), 3),
                 "emitter_radiance": torch.from_numpy(emi["emitter_radiance"])}, emi_path)
     H, W = args.height, args.width
-    views = []
+    names, frames, K0 = [], [], None
     for i in range(args.views):
         K, c2w = synth.camera(H, W, (i * 32) // args.views, n_views=32)
-        views.append({"K": np.asarray(K).reshape(-1).tolist(), "c2w": np.asarray(c2w).reshape(-1).tolist()})
-    cam_path = os.path.join(args.out, "cameras.json")
-    json.dump({"img_hw": [H, W], "views": views}, open(cam_path, "w"))
+        K0 = np.asarray(K, np.float64)
+        m = np.eye(4); m[:3, :4] = np.asarray(c2w, np.float64); m[:3, 1:3] *= -1          # OpenCV -> the OpenGL convention transforms_all.json stores
+        names.append("DSC%05d.JPG" % i)
+        frames.append({"file_path": "images/" + names[-1], "transform_matrix": m.tolist()})
+    json.dump({"train": names, "test": []}, open(os.path.join(psdf_dir, "train_test_lists.json"), "w"))
+    json.dump({"fl_x": float(K0[0, 0]), "fl_y": float(K0[1, 1]), "cx": float(K0[0, 2]), "cy": float(K0[1, 2]), "h": H, "w": W, "frames": frames[::-1]},        # (stored out of order: the LIST decides)
+              open(os.path.join(psdf_dir, "transforms_all.json"), "w"))
     print("# dataset written in %.1f s: %d triangles, %d views of %dx%d" % (time.time() - t0, len(f), args.views, W, H), file=sys.stderr)
 
     for cfg in args.configs.split(","):
         comp, den = cfg.split(":")
         out_dir = os.path.join(args.out, "shading_" + cfg.replace(":", "_"))
-        cmd = [sys.executable, "-m", "iris_amd.bake_shading", "--scene", scene_dir, "--slf_path", slf_path, "--emitter_path", emi_path, "--output", out_dir,
-               "--dataset", "generic", "--cameras", cam_path, "--compression", comp, "--denoise", den]
+        # scripts/scannetpp/bathroom2/train.sh:49-54's argument list (+ the two additions under test)
+        cmd = [sys.executable, "-m", "iris_amd.bake_shading", "--dataset_root", args.out, "--scene", SCENE, "--dataset", "scannetpp", "--res_scale", "1.0",
+               "--slf_path", slf_path, "--emitter_path", emi_path, "--output", out_dir, "--compression", comp, "--denoise", den]
         t = time.time()
         r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True)
         dt = time.time() - t
@@ -84,7 +91,7 @@ def main():
         size = sum(os.path.getsize(os.path.join(d, x)) for d, _, fs in os.walk(out_dir) for x in fs)
         from iris_amd import bake_shading as bs
         rays = args.views * H * W * (bs.SPP_DIFFUSE + sum(bs.SPPS_SPECULAR))     # upper bound: every pixel valid
-        print(json.dumps({"config": {"compression": comp, "denoise": den, "views": args.views, "image": [W, H], "triangles": int(len(f)), "host_cpus": os.cpu_count()},
+        print(json.dumps({"config": {"compression": comp, "denoise": den, "views": args.views, "image": [W, H], "triangles": int(len(f)), "host_cpus": os.cpu_count(), "command": "python -m iris_amd.bake_shading --dataset_root R --scene S --dataset scannetpp --res_scale 1.0 --slf_path ... --emitter_path ... --output ... (scripts/scannetpp/bathroom2/train.sh:49-54)"},
                           "wall_s": round(dt, 2), "s_per_view_incl_startup": round(dt / args.views, 3), "cli_report": inner[-1] if inner else None,
                           "files": n_files, "bytes_written": size, "upper_bound_Mrays_per_s": round(rays / dt / 1e6, 1)}), flush=True)
         shutil.rmtree(out_dir, ignore_errors=True)
