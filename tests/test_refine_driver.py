@@ -193,3 +193,52 @@ def test_refine_cli_runs_from_a_checkpoint(tmp_path):
     np.testing.assert_array_equal(got, ref["diffuse"].reshape(H, W, 3).cpu().numpy())
     with pytest.raises(L.IrisError):
         rs.main([a for a in argv if a not in ("--ckpt", ckpt)])          # neither --ckpt nor --material
+
+
+def test_refine_cli_scannetpp_runs_the_reference_command_line(tmp_path):
+    """scripts/scannetpp/bathroom2/train.sh:97-103's argument list, unchanged: `--dataset_root R --scene S --dataset scannetpp --res_scale s --slf_path ... --emitter_path ...
+    --ckpt ... --output ...` -- the mesh from R/data/S/scans/scene.ply, the train views from R/data/S/psdf (refine_shading.py:52-77), the material network from the checkpoint --
+    over the 13 files a bake of the same command line wrote (the reference runs both scripts on one --output)."""
+    from iris_amd import refine_shading as rs
+    from iris_amd import bake_shading as bs
+    from iris_amd import _lib as L
+    from iris_amd.model.slf import VoxelSLF
+    from iris_amd.utils import cameras, exr
+    from test_exr_cli import _scannetpp_tree
+    g = _scannetpp_tree(tmp_path, "45b0dac5e3")
+    b = golden("bake_box.npz"); p = golden("pt_single.npz")
+    verts = (b["verts"] - b["verts"].mean(0)) * 4.0
+    os.makedirs(str(tmp_path / "data" / "45b0dac5e3" / "scans"))
+    with open(str(tmp_path / "data" / "45b0dac5e3" / "scans" / "scene.ply"), "w") as fh:
+        fh.write("ply\nformat ascii 1.0\nelement vertex {}\nproperty float x\nproperty float y\nproperty float z\nelement face {}\n"
+                 "property list uchar int vertex_indices\nend_header\n".format(len(verts), len(b["faces"])))
+        for v in verts:
+            fh.write("{!r} {!r} {!r}\n".format(*(float(c) for c in v)))
+        for f in b["faces"]:
+            fh.write("3 {} {} {}\n".format(*f))
+    mask = np.ones((8, 8, 8), bool)
+    slf = VoxelSLF(torch.from_numpy(mask), -9.0, 9.0)
+    slf.radiance[:] = torch.linspace(0.1, 1.0, slf.radiance.numel()).reshape(slf.radiance.shape)
+    K = int(b["is_emitter"].sum())
+    ev = torch.from_numpy((p["emitter_vertices"] - b["verts"].mean(0)) * 4.0).float()
+    ep, sp = str(tmp_path / "emitter.pth"), str(tmp_path / "vslf.npz")
+    torch.save({"is_emitter": torch.from_numpy(b["is_emitter"]), "emitter_vertices": ev, "emitter_area": torch.from_numpy(b["emitter_area"]) * 16,
+                "emitter_normal": torch.zeros(K, 3), "emitter_radiance": torch.from_numpy(b["emitter_radiance"])}, ep)
+    torch.save({"mask": torch.from_numpy(mask), "voxel_min": -9.0, "voxel_max": 9.0, "weight": slf.state_dict()}, sp)
+    gen = torch.Generator().manual_seed(5)
+    ckpt = str(tmp_path / "last_0.ckpt")
+    torch.save({"state_dict": {"material.mlp.params": (torch.rand(int(L.lib().iris_ngp_n_params()), generator=gen) * 2 - 1) * 0.3, "emitter.radiance": torch.zeros(1, 3)}}, ckpt)
+    out = str(tmp_path / "outputs" / "shading")
+    s = float(g["rays_res_scale"])
+    common = ["--dataset_root", str(tmp_path), "--scene", "45b0dac5e3", "--dataset", "scannetpp", "--res_scale", str(s), "--slf_path", sp, "--emitter_path", ep]
+    bs.main(common + ["--output", out, "--spp_diffuse", "4", "--spps_specular", "2", "2", "2", "2", "2", "2", "--denoise", "none", "--compression", "none"])     # train.sh:49-54
+    before = exr.read_exr(bs.output_files(out, 1)[0]).copy()
+    rs.main(common + ["--ckpt", ckpt, "--output", out, "--spp_diffuse", "4", "--spp_specular", "2", "--indir_depth", "2", "--denoise", "none", "--compression", "none"])   # train.sh:97-103
+    img_hw, views = cameras.load_scannetpp(str(tmp_path), "45b0dac5e3", s)
+    assert len(views) == 5
+    for im_id in range(5):
+        files = bs.output_files(out, im_id)
+        assert all(os.path.exists(f) for f in files) and os.path.exists(os.path.join(out, "diffuse", "{:03d}.refined".format(im_id)))
+        a = exr.read_exr(files[0])
+        assert a.shape == (img_hw[0], img_hw[1], 3) and np.isfinite(a).all()
+    assert not np.array_equal(exr.read_exr(bs.output_files(out, 1)[0]), before)          # the refined maps replaced the bake's, in place
