@@ -169,3 +169,4 @@ def test_a_rank_dying_mid_run_ends_the_job_quickly():
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]                 # no result line from a failed job
     ok, dt_ok = _two_ranks()
     assert dt < dt_ok + 30.0, (dt, dt_ok)                                                       # ended about as fast as a good run ends
+
